@@ -1,0 +1,165 @@
+"""Oracle (test infrastructure only) for the protein-style (EvoDiff-like) D3PM.
+
+Functional restatement, in eager PyTorch-CPU ops with the reference's dtypes
+(float32 betas, float64 after the softmax) and its per-sequence Python loops,
+of ``protein_generation/utils.py`` (schedule, tables, forward corruption),
+``protein_generation/losses.py`` (LVB loss, single-sequence and MSA variants)
+and the step maths of ``protein_generation/generate.py``.
+
+``torch.multinomial(P, 1)`` on CPU draws ``E = empty_like(P).exponential_(1)``
+and returns ``argmax(P / E)``; the samplers here take ``E`` explicitly so that
+a recorded draw can be replayed.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+# protein_generation/constants.py:1-10
+ALPHABET = "ACDEFGHIKLMNPQRSTVWYX-#!"   # PROTEIN_ALPHABET, 24 symbols
+K_MSA = 22                              # len(MSA_AAS): 20 aa + X + gap
+
+
+def beta_schedule(num_steps: int, start: float = 1e-5, end: float = 0.999,
+                  schedule: str = "linear") -> torch.Tensor:
+    """utils.py:28-41 (float32 throughout)."""
+    if schedule == "linear":
+        return torch.linspace(start, end, num_steps)
+    if schedule == "cosine":
+        b = torch.linspace(np.pi / 2, 0, num_steps)
+        return torch.cos(b) * (end - start) + start
+    if schedule == "sohl-dickstein":
+        b = torch.linspace(0, num_steps - 1, num_steps)
+        return 1 / (num_steps - b + 1)
+    raise NotImplementedError(schedule)
+
+
+def running_products(mats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """utils.py:7-18 (``cumprod_matrix``)."""
+    out = [mats[0]]
+    acc = mats[0]
+    for i in range(len(mats) - 1):
+        acc = torch.mm(acc, mats[i + 1])
+        out.append(acc)
+    return out
+
+
+def uniform_tables(K: int = K_MSA, num_steps: int = 500, schedule: str = "sohl-dickstein"):
+    """utils.py:65-83 (``Tokenizer.q_uniform_schedule``): returns (Q_bar, Q_t),
+    both [T,K,K] float64; the off-diagonal is float32 arithmetic promoted."""
+    betas = beta_schedule(num_steps=num_steps, schedule=schedule)
+    steps = []
+    for i in range(len(betas)):
+        off = torch.ones((K, K)) / K * betas[i]
+        norm = 1 - off.sum(axis=0)
+        steps.append(torch.tensor(np.identity(K)) * norm + off)
+    q_bar = torch.stack(running_products(steps))
+    return q_bar, torch.stack(steps)
+
+
+def tokenize(seq: str) -> np.ndarray:
+    """utils.py:85-86."""
+    lut = {c: i for i, c in enumerate(ALPHABET)}
+    return np.array([lut[c] for c in seq])
+
+
+def untokenize(tokens) -> str:
+    """utils.py:88-92."""
+    return "".join(ALPHABET[int(i)] for i in tokens)
+
+
+def one_hot(tokens: torch.Tensor, K: int = K_MSA) -> torch.Tensor:
+    """utils.py:94-97."""
+    return torch.nn.functional.one_hot(tokens, num_classes=K).to(torch.double)
+
+
+def corrupt(x0_onehot: torch.Tensor, q_bar_t: torch.Tensor, expo: torch.Tensor):
+    """utils.py:44-52 (``sample_transition_matrix``) with the exponential draw
+    of ``torch.multinomial`` passed in: returns (x_t [L], probs [L,K])."""
+    p = torch.mm(x0_onehot, q_bar_t)
+    return torch.argmax(p / expo, dim=1), p
+
+
+def _posterior_pieces(pred64, x_t_oh, x0_oh, Qt, Qm):
+    """losses.py:70-76 / generate.py:34-38: A, B and the p-squared marginal."""
+    K = Qt.shape[0]
+    A = torch.mm(x_t_oh, torch.t(Qt))
+    Bm = torch.mm(x0_oh, Qm) if x0_oh is not None else None
+    Qe = Qm.unsqueeze(0).expand(A.shape[0], K, K)
+    q_t = torch.mul(A.unsqueeze(1), torch.mul(pred64.unsqueeze(2), Qe))
+    marg = torch.bmm(torch.transpose(q_t, 1, 2), pred64.unsqueeze(2)).squeeze()
+    return A, Bm, marg
+
+
+def lvb_per_sequence(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar,
+                     K: int = K_MSA, tmax: int = 500, msa: bool = False) -> torch.Tensor:
+    """losses.py:48-90 (and :120-153 with ``msa=True``): one loss per batch
+    element, branch on t==1 / t==tmax / else."""
+    kl = torch.nn.KLDivLoss(reduction="batchmean", log_target=False)
+    ce = torch.nn.CrossEntropyLoss(weight=None, reduction="mean")
+    p = torch.nn.functional.softmax(predictions[..., :K], dim=-1)
+    out = []
+    for i in range(tgt.shape[0]):
+        ti = timestep[i]
+        if ti == 1:
+            out.append(ce(predictions[i].reshape(-1, predictions.shape[-1]), tgt[i].reshape(-1)))
+        elif ti == tmax:
+            prior = torch.ones_like(torch.empty(*q[i].shape)) / K
+            out.append(kl(prior.log(), q[i]))
+        else:
+            pred = p[i].reshape(-1, K).to(torch.float64)
+            x_t = src_onehot[i][..., :K].reshape(-1, K)
+            x_0 = tgt_onehot[i][..., :K].reshape(-1, K)
+            A, Bm, marg = _posterior_pieces(pred, x_t, x_0, Q[ti], Q_bar[ti - 1])
+            num = torch.mul(A, Bm)
+            Qden = Q_bar[ti - 1] if msa else Q_bar[ti]      # losses.py:148 vs :79
+            den = torch.bmm(torch.mm(x_0, Qden).unsqueeze(1), x_t.unsqueeze(2))
+            post = num / den.squeeze().unsqueeze(1)
+            marg = marg / marg.sum(dim=1, keepdim=True)
+            out.append(kl(marg.log(), post))
+    return torch.stack(out)
+
+
+def lvb(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, **kw) -> torch.Tensor:
+    """losses.py:88-93: sum of the per-sequence losses over the batch size."""
+    per = lvb_per_sequence(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, **kw)
+    return per.sum() / tgt.shape[0]
+
+
+def reverse_marginal(logits: torch.Tensor, x_t: torch.Tensor, Qt: torch.Tensor, Qm: torch.Tensor,
+                     K: int = K_MSA) -> torch.Tensor:
+    """generate.py:28-39 for one sequence: normalised p_theta(x_{t-1}|x_t)
+    [L,K] float64 from denoiser logits [L,n_tokens]."""
+    p = torch.nn.functional.softmax(logits[:, :K], dim=-1).to(torch.float64)
+    _, _, marg = _posterior_pieces(p, one_hot(x_t, K), None, Qt, Qm)
+    return marg / marg.sum(dim=1, keepdim=True)
+
+
+def reverse_step(logits: torch.Tensor, x_t: torch.Tensor, t: int, Q: torch.Tensor, Q_bar: torch.Tensor,
+                 expo: torch.Tensor, K: int = K_MSA) -> torch.Tensor:
+    """generate.py:32-41 for a batch: logits [B,L,n_tokens], x_t [B,L],
+    expo [B,L,K] float64 -> x_{t-1} [B,L] int64."""
+    out = x_t.clone()
+    for i in range(x_t.shape[0]):
+        P = reverse_marginal(logits[i], x_t[i], Q[t], Q_bar[t - 1], K)
+        out[i] = torch.argmax(P / expo[i], dim=1)
+    return out
+
+
+def generate(model, Q, Q_bar, timesteps: int, x_init: torch.Tensor, expo_fn, K: int = K_MSA):
+    """generate.py:21-44: the full reverse loop t = T-1 .. 1 from ``x_init``;
+    ``expo_fn(step, i)`` supplies the [L,K] exponential draw of sequence i."""
+    sample = x_init.clone()
+    B = sample.shape[0]
+    ts = torch.linspace(timesteps - 1, 1, int((timesteps - 1) / 1), dtype=int)
+    with torch.no_grad():
+        for step, t in enumerate(ts):
+            logits = model(sample, torch.tensor([t] * B))
+            nxt = sample.clone()
+            for i in range(B):
+                P = reverse_marginal(logits[i], sample[i], Q[t], Q_bar[t - 1], K)
+                nxt[i] = torch.argmax(P / expo_fn(step, i), dim=1)
+            sample = nxt
+    return sample, [untokenize(s) for s in sample]

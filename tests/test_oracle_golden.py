@@ -1,0 +1,177 @@
+"""The oracle against the golden vectors captured from the reference itself.
+
+These pin the CPU restatement (oracle/) to the reference; the GPU tests then
+pin the HIP path to the oracle and to the same vectors."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import image_style as im
+from oracle import protein_style as pr
+from conftest import golden
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def T_(a, dtype=None):
+    t = torch.from_numpy(np.array(a))
+    return t if dtype is None else t.to(dtype)
+
+
+def build_like(g, kind, num_bits, bands=None):
+    return im.build_process(T_(g["betas"]), kind, num_bits, bands, hybrid_coeff=0.001)
+
+
+def check_downstream(p, g, exact=True):
+    x0, t = T_(g["x0"]), T_(g["t"])
+    noise, logits, noise2, w = T_(g["noise"]), T_(g["logits"]), T_(g["noise2"]), T_(g["w"])
+    eq = (lambda a, b: np.testing.assert_array_equal(a.numpy(), b)) if exact else \
+         (lambda a, b: np.testing.assert_allclose(a.numpy(), b, rtol=1e-6, atol=1e-7))
+    eq(im.forward_probs(p, x0, t), g["q_probs"])
+    x_t = im.forward_sample(p, x0, t, noise)
+    np.testing.assert_array_equal(x_t.numpy(), g["x_t"])
+    eq(im.posterior_logits(p, x0, x_t, t, False), g["post_true"])
+    eq(im.posterior_logits(p, logits, x_t, t, True), g["post_model"])
+    eq(im.model_logits(p, logits, x_t, t)[0], g["p_logits"])
+    eq(im.vb_terms(p, logits, x0, x_t, t)[0], g["vb"])
+    eq(im.ce_start(x0, logits), g["ce"])
+    for lt in ("hybrid", "kl", "cross_entropy_x_start"):
+        p.loss_type = lt
+        lg = logits.clone().requires_grad_(True)
+        losses = im.losses_given_xt(p, lg, x0, x_t, t)
+        eq(losses.detach(), g["losses_" + lt])
+        (gr,) = torch.autograd.grad((losses * w).sum(), lg)
+        eq(gr, g["grad_w_" + lt])
+    p.loss_type = "hybrid"
+    s, probs = im.reverse_step(p, logits, x_t, t, noise2)
+    np.testing.assert_array_equal(s.numpy(), g["p_sample"])
+    eq(probs, g["p_sample_probs"])
+    if g["prior_bpd"].size:
+        eq(im.prior_term(p, x0), g["prior_bpd"])
+
+
+def test_image_uniform_k32_tables_and_steps():
+    g = golden("image_uniform_k32")
+    p = build_like(g, "uniform", 5)
+    assert sha(p.q_mats.numpy()) == str(g["q_mats_sha256"])
+    assert sha(p.qT_onestep.contiguous().numpy()) == str(g["qT_onestep_sha256"])
+    ts = g["slice_t"]
+    np.testing.assert_array_equal(p.q_mats.numpy()[ts], g["q_mats_slices"])
+    check_downstream(p, g)
+
+
+def test_image_uniform_cosine_tables():
+    g = golden("image_uniform_k32_cosine_tables")
+    p = build_like(g, "uniform", 5)
+    assert sha(p.q_mats.numpy()) == str(g["q_mats_sha256"])
+
+
+def test_image_absorbing_k32():
+    g = golden("image_absorbing_k32")
+    p = build_like(g, "absorbing", 5)
+    assert sha(p.q_mats.numpy()) == str(g["q_mats_sha256"])
+    assert sha(p.qT_onestep.contiguous().numpy()) == str(g["qT_onestep_sha256"])
+    check_downstream(p, g)
+    # properties the reference never checked: rows sum to 1, mass ends in K//2
+    np.testing.assert_allclose(p.q_mats.sum(-1).numpy(), 1.0, atol=1e-12)
+    assert p.q_mats[-1, :, 16].min() > 1 - 1e-9
+
+
+@pytest.mark.parametrize("name,kind,bands", [("gaussian_k16_full", "gaussian", None),
+                                             ("gaussian_k16_b5", "gaussian", 5),
+                                             ("uniform_k16_b3", "uniform", 3)])
+def test_image_small_full_tables(name, kind, bands):
+    g = golden("image_" + name)
+    p = build_like(g, kind, 4, bands)
+    np.testing.assert_array_equal(p.q_mats.numpy(), g["q_mats"])
+    np.testing.assert_array_equal(p.qT_onestep.contiguous().numpy(), g["qT_onestep"])
+    check_downstream(p, g)
+
+
+def test_image_gaussian_k256_tables_and_steps():
+    g = golden("image_gaussian_k256")
+    p = build_like(g, "gaussian", 8)
+    assert sha(p.q_mats.numpy()) == str(g["q_mats_sha256"])
+    ts = g["slice_t"]
+    np.testing.assert_array_equal(p.qT_onestep.contiguous().numpy()[ts], g["qT_onestep_slices"])
+    check_downstream(p, g)
+
+
+def test_image_misc():
+    g = golden("image_misc")
+    np.testing.assert_array_equal(im.make_betas(1e-4, 0.02, 1000, "linear").numpy(), g["betas_linear"])
+    np.testing.assert_array_equal(im.make_betas(0, 0, 500, "cosine").numpy(), g["betas_cosine"])
+    np.testing.assert_array_equal(im.make_betas(0, 0, 500, "jsd").numpy(), g["betas_jsd"])
+    np.testing.assert_array_equal(im.log_min_exp(T_(g["lme_a"]), T_(g["lme_b"])).numpy(), g["lme_out"])
+    with pytest.raises(NotImplementedError):
+        im.make_betas(0, 1, 4, "nope")
+    with pytest.raises(ValueError):
+        im.build_process(torch.tensor([0.0, 0.5]), "uniform", 2)
+    with pytest.raises(ValueError):
+        im.build_process(torch.tensor([0.1, 0.5]), "bogus", 2)
+
+
+# ---------------------------------------------------------------------------
+def test_protein_tables():
+    g = golden("protein_tables_k22")
+    for s in ("sohl", "linear", "cosine"):
+        name = {"sohl": "sohl-dickstein"}.get(s, s)
+        np.testing.assert_array_equal(pr.beta_schedule(500, schedule=name).numpy(), g["betas_" + s])
+    qb, qt = pr.uniform_tables(22, 500, "sohl-dickstein")
+    assert sha(qb.numpy()) == str(g["Q_bar_sha256"])
+    assert sha(qt.numpy()) == str(g["Q_t_sha256"])
+    g2 = golden("protein_tables_k22_linear60")
+    qb, qt = pr.uniform_tables(22, 60, "linear")
+    np.testing.assert_array_equal(qb.numpy(), g2["Q_bar"])
+    np.testing.assert_array_equal(qt.numpy(), g2["Q_t"])
+    # the float32 off-diagonal quirk: rows do not sum to exactly one
+    assert abs(qt[0].sum(-1) - 1).max() > 1e-9
+
+
+def test_protein_forward_and_lvb():
+    g = golden("protein_lvb_blat")
+    qb, qt = pr.uniform_tables(22, 500, "sohl-dickstein")
+    x0, x_t, ts = T_(g["x0"]), T_(g["x_t"]), T_(g["timestep"])
+    for i in range(x0.shape[0]):
+        s, p = pr.corrupt(pr.one_hot(x0[i]), qb[min(int(ts[i]), 499)], T_(g["expo"][i]))
+        np.testing.assert_array_equal(s.numpy(), g["x_t"][i])
+        np.testing.assert_array_equal(p.numpy(), g["q"][i])
+    for n_tok in (22, 24):
+        pred = T_(g[f"pred{n_tok}"]).requires_grad_(True)
+        args = (pr.one_hot(x_t), T_(g["q"]), pred, x0, pr.one_hot(x0), ts, qt, qb)
+        per = pr.lvb_per_sequence(*args)
+        np.testing.assert_array_equal(per.detach().numpy(), g[f"per_seq{n_tok}"])
+        total = pr.lvb(*args)
+        np.testing.assert_array_equal(total.detach().numpy(), g[f"lvb{n_tok}"])
+        (gr,) = torch.autograd.grad(total, pred)
+        np.testing.assert_array_equal(gr.numpy(), g[f"grad{n_tok}"])
+
+
+def test_protein_lvb_msa():
+    g = golden("protein_lvb_msa")
+    qb, qt = pr.uniform_tables(22, 500, "sohl-dickstein")
+    pred = T_(g["pred"]).requires_grad_(True)
+    x0, x_t = T_(g["x0"]), T_(g["x_t"])
+    total = pr.lvb(pr.one_hot(x_t), T_(g["q"]), pred, x0, pr.one_hot(x0), T_(g["timestep"]), qt, qb, msa=True)
+    np.testing.assert_array_equal(total.detach().numpy(), g["lvb"])
+    (gr,) = torch.autograd.grad(total, pred)
+    np.testing.assert_array_equal(gr.numpy(), g["grad"])
+
+
+def test_protein_generate_replay():
+    g = golden("protein_generate")
+    emb, tvec = T_(g["emb"]), T_(g["tvec"])
+    model = lambda x, tt: emb[x] + tvec[tt][:, None, :]
+    expo = T_(g["expo"])
+    sample, strings = pr.generate(model, T_(g["Q_t"]), T_(g["Q_bar"]), 20, T_(g["x_init"]),
+                                  lambda step, i: expo[step, i])
+    np.testing.assert_array_equal(sample.numpy(), g["sample"])
+    assert strings == [str(s) for s in g["strings"]]
+    # one batched step equals the per-sequence loop
+    x = T_(g["x_init"])
+    one = pr.reverse_step(model(x, torch.tensor([19] * 3)), x, 19, T_(g["Q_t"]), T_(g["Q_bar"]), expo[0])
+    assert one.shape == x.shape

@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Runs only in the development container, where the upstream reference tree is
+mounted read-only (default /root/reference, override with D3PM_REFERENCE).
+The two reference sub-projects both have a top-level ``utils.py``, so each is
+imported in its own child process (``--part image`` / ``--part protein``).
+Only inputs and outputs are written (small ``.npz`` files); no reference source
+is copied.  The GPU box never runs this script and never sees the reference.
+
+    python tools/make_golden.py            # regenerate everything
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("D3PM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+FASTA = os.path.join(REF, "protein_generation", "generated_sequences", "generated_samples_string.fasta")
+ALPHABET = "ACDEFGHIKLMNPQRSTVWYX-#!"
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def fasta_tokens(n: int) -> np.ndarray:
+    seqs = [ln.strip() for ln in open(FASTA) if not ln.startswith(">")][:n]
+    lut = {c: i for i, c in enumerate(ALPHABET)}
+    return np.array([[lut[c] for c in s] for s in seqs], dtype=np.int64)
+
+
+def save(name: str, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrs)} arrays")
+
+
+SLICE_T = lambda T: sorted({0, 1, 2, T // 2, T - 2, T - 1})
+
+
+# ---------------------------------------------------------------------------
+# image-style reference (d3pm/)
+# ---------------------------------------------------------------------------
+def part_image():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(REF, "d3pm"))
+    import torch
+    import diffusion_discrete as dd   # the reference
+    import utils as ru                # the reference's d3pm/utils.py
+
+    torch.set_num_threads(8)
+    import torch as _t
+    info = np.array([_t.__version__, np.__version__])
+
+    def table_arrays(d, prefix=""):
+        T = d.num_timesteps
+        ts = SLICE_T(T)
+        qm = d.q_mats.numpy()
+        qt = d.transpose_q_onestep_mats.contiguous().numpy()
+        return {prefix + "slice_t": np.array(ts), prefix + "q_mats_slices": qm[ts],
+                prefix + "qT_onestep_slices": qt[ts],
+                prefix + "q_mats_sha256": np.array(sha(qm)), prefix + "qT_onestep_sha256": np.array(sha(qt))}
+
+    def downstream(d, x0, t, seed, frozen_scale=1.0):
+        """Every per-step method on explicit noise and frozen denoiser logits."""
+        g = torch.Generator().manual_seed(seed)
+        K = d.num_pixel_vals
+        noise = torch.rand(x0.shape + (K,), generator=g)
+        logits = (torch.randn(x0.shape + (K,), generator=g) * frozen_scale).requires_grad_(True)
+        noise2 = torch.rand(x0.shape + (K,), generator=g)
+        w = torch.rand(x0.shape[0], generator=g) + 0.5
+        model_fn = lambda x, tt: logits
+        out = {}
+        out["x0"], out["t"], out["noise"], out["logits"] = x0.numpy(), t.numpy(), noise.numpy(), logits.detach().numpy()
+        out["noise2"], out["w"] = noise2.numpy(), w.numpy()
+        out["q_probs"] = d.q_probs(x0, t).numpy()
+        x_t = d.q_sample(x0, t, noise)
+        out["x_t"] = x_t.numpy()
+        lg = torch.log(d.q_probs(x0, t) + d.eps) + (-torch.log(-torch.log(torch.clip(noise, min=torch.finfo(noise.dtype).tiny, max=1.))))
+        top2 = torch.topk(lg, 2, dim=-1).values
+        out["q_sample_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+        out["post_true"] = d.q_posterior_logits(x0, x_t, t, x_start_logits=False).numpy()
+        out["post_model"] = d.q_posterior_logits(logits.detach(), x_t, t, x_start_logits=True).numpy()
+        ml, px0 = d.p_logits(model_fn, x=x_t, t=t)
+        out["p_logits"] = ml.detach().numpy()
+        vb, _ = d.vb_terms_bpd(model_fn, x_start=x0, x_t=x_t, t=t)
+        out["vb"] = vb.detach().numpy()
+        out["ce"] = d.cross_entropy_start(x0, logits).detach().numpy()
+        # training_losses draws its own noise/t; replay its body on the recorded x_t
+        for lt in ("hybrid", "kl", "cross_entropy_x_start"):
+            d.loss_type = lt
+            if lt == "kl":
+                losses, _ = d.vb_terms_bpd(model_fn=model_fn, x_start=x0, x_t=x_t, t=t)
+            elif lt == "cross_entropy_x_start":
+                _, pl = d.p_logits(model_fn, x=x_t, t=t)
+                losses = d.cross_entropy_start(x_start=x0, pred_x_start_logits=pl)
+            else:
+                vbl, pl = d.vb_terms_bpd(model_fn=model_fn, x_start=x0, x_t=x_t, t=t)
+                losses = vbl + d.hybrid_coeff * d.cross_entropy_start(x_start=x0, pred_x_start_logits=pl)
+            out["losses_" + lt] = losses.detach().numpy()
+            (gr,) = torch.autograd.grad((losses * w).sum(), logits)
+            out["grad_w_" + lt] = gr.numpy()
+        d.loss_type = "hybrid"
+        sample, probs = d.p_sample(model_fn, x=x_t, t=t, noise=noise2)
+        out["p_sample"], out["p_sample_probs"] = sample.numpy(), probs.numpy()
+        mask = (t != 0).float().view(-1, 1, 1, 1, 1)
+        lg = ml.detach() + mask * (-torch.log(-torch.log(torch.clip(noise2, min=torch.finfo(noise2.dtype).tiny, max=1.))))
+        top2 = torch.topk(lg, 2, dim=-1).values
+        out["p_sample_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+        out["prior_bpd"] = d.prior_bpd(x0).numpy() if d.transition_mat_type != "absorbing" else np.zeros(0)
+        return out
+
+    def make(kind, num_bits, betas, bands=None, lam=0.001):
+        return dd.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=num_bits,
+                                    transition_bands=bands, model_prediction="x_start", model_output="logits",
+                                    loss_type="hybrid", hybrid_coeff=lam, device="cpu")
+
+    toks = fasta_tokens(6)[:, :96]
+    pos = np.arange(toks.shape[1])[None, :]
+
+    # --- uniform, K=32, T=500 (jsd) : the protein-synthetic configuration -----
+    betas = dd.generate_betas(0.0, 0.0, 500, "jsd")
+    d = make("uniform", 5, betas)
+    x0 = torch.tensor(((toks * 3 + pos) % 32).astype(np.int32)).reshape(6, 96, 1, 1)
+    t = torch.tensor([0, 1, 2, 250, 498, 499], dtype=torch.int32)
+    arrs = {"betas": betas.numpy(), "torch_numpy_versions": info, **table_arrays(d), **downstream(d, x0, t, 11)}
+    save("image_uniform_k32", **arrs)
+
+    # --- uniform, cosine betas: tables only --------------------------------
+    betas = dd.generate_betas(0.0, 0.0, 500, "cosine")
+    d = make("uniform", 5, betas)
+    save("image_uniform_k32_cosine_tables", betas=betas.numpy(), **table_arrays(d))
+
+    # --- absorbing, K=32, T=500: builder crashes in the reference (torch.full(shape=)),
+    #     so inject tables built from its evident formula and run every downstream method.
+    betas = dd.generate_betas(0.0, 0.0, 500, "jsd")
+    d = make("uniform", 5, betas)
+    K = 32
+    steps = []
+    for tt in range(500):
+        m = np.diag(np.full(K, 1.0 - betas[tt].item()))
+        m[:, K // 2] += betas[tt].item()
+        steps.append(m)
+    cur = steps[0]
+    chain = [cur]
+    for tt in range(1, 500):
+        cur = np.tensordot(cur, steps[tt], axes=[[1], [0]])
+        chain.append(cur)
+    d.q_mats = torch.tensor(np.stack(chain))
+    d.transpose_q_onestep_mats = torch.tensor(np.stack(steps)).permute(0, 2, 1)
+    d.transition_mat_type = "absorbing"
+    arrs = {"betas": betas.numpy(), **table_arrays(d), **downstream(d, x0, t, 12)}
+    save("image_absorbing_k32", **arrs)
+
+    # --- gaussian, K=256, T=1000, linear 1e-4 -> 0.02: the image configuration ---
+    betas = dd.generate_betas(1e-4, 0.02, 1000, "linear")
+    d = make("gaussian", 8, betas)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randint(0, 256, (4, 6, 6, 1), generator=g, dtype=torch.int32)
+    t = torch.tensor([0, 1, 500, 999], dtype=torch.int32)
+    arrs = {"betas": betas.numpy(), **table_arrays(d), **downstream(d, x0, t, 13, frozen_scale=2.0)}
+    save("image_gaussian_k256", **arrs)
+
+    # --- small full tables: gaussian (full band and 5 bands), banded uniform ------
+    for name, kind, bands in (("gaussian_k16_full", "gaussian", None), ("gaussian_k16_b5", "gaussian", 5),
+                              ("uniform_k16_b3", "uniform", 3)):
+        betas = dd.generate_betas(0.002, 0.3, 40, "linear")
+        d = make(kind, 4, betas, bands=bands)
+        g = torch.Generator().manual_seed(6)
+        x0 = torch.randint(0, 16, (4, 5, 3, 2), generator=g, dtype=torch.int64)
+        t = torch.tensor([0, 1, 20, 39], dtype=torch.int64)
+        arrs = {"betas": betas.numpy(), "q_mats": d.q_mats.numpy(),
+                "qT_onestep": d.transpose_q_onestep_mats.contiguous().numpy(),
+                "bands": np.array(-1 if bands is None else bands), **downstream(d, x0, t, 14)}
+        save("image_" + name, **arrs)
+
+    # --- schedules and helpers ------------------------------------------------------
+    g = torch.Generator().manual_seed(7)
+    a = -torch.rand(64, generator=g) * 3
+    b = a - torch.rand(64, generator=g) * 2 - 1e-3
+    loc = torch.rand(3, 4, 4, 1, generator=g) * 2 - 1
+    log_scale = torch.randn(3, 4, 4, 1, generator=g) * 0.5
+    d = make("uniform", 4, dd.generate_betas(0.0, 0.0, 20, "jsd"))
+    d.device = "cpu"
+    save("image_misc",
+         betas_linear=dd.generate_betas(1e-4, 0.02, 1000, "linear").numpy(),
+         betas_cosine=dd.generate_betas(0.0, 0.0, 500, "cosine").numpy(),
+         betas_jsd=dd.generate_betas(0.0, 0.0, 500, "jsd").numpy(),
+         lme_a=a.numpy(), lme_b=b.numpy(), lme_out=ru.log_min_exp(a, b).numpy(),
+         logistic_loc=loc.numpy(), logistic_log_scale=log_scale.numpy(),
+         logistic_logits=d._get_logits_from_logistic_pars(loc, log_scale).numpy())
+
+
+# ---------------------------------------------------------------------------
+# protein-style reference (protein_generation/)
+# ---------------------------------------------------------------------------
+def part_protein():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(REF, "protein_generation"))
+    # generate.py imports dataset.py, which parses a Colab path at import time.
+    stub = types.ModuleType("dataset")
+    stub.ProteinSequenceDatasetMSA = stub.CollaterMSA = object
+    sys.modules["dataset"] = stub
+    import torch
+    import utils as pu
+    import losses as pl
+    import generate as pg
+
+    torch.set_num_threads(8)
+    tok = pu.Tokenizer()
+    K = tok.K
+    assert K == 22
+
+    # --- schedules and tables --------------------------------------------------------
+    Qb, Qt = tok.q_uniform_schedule(num_steps=500, schedule="sohl-dickstein")
+    ts = SLICE_T(500)
+    save("protein_tables_k22",
+         betas_sohl=pu._beta_schedule(500, schedule="sohl-dickstein").numpy(),
+         betas_linear=pu._beta_schedule(500, schedule="linear").numpy(),
+         betas_cosine=pu._beta_schedule(500, schedule="cosine").numpy(),
+         slice_t=np.array(ts), Q_bar_slices=Qb.numpy()[ts], Q_t_slices=Qt.numpy()[ts],
+         Q_bar_sha256=np.array(sha(Qb.numpy())), Q_t_sha256=np.array(sha(Qt.numpy())))
+    Qb_lin, Qt_lin = tok.q_uniform_schedule(num_steps=60, schedule="linear")
+    save("protein_tables_k22_linear60", Q_bar=Qb_lin.numpy(), Q_t=Qt_lin.numpy())
+
+    # --- forward corruption with the multinomial draw recorded -----------------------
+    toks = torch.tensor(fasta_tokens(8))
+    B, L = toks.shape
+    tsteps = [1, 2, 250, 499, 500, 37, 1, 420]
+    x_t, q_x, E = [], [], []
+    for i in range(B):
+        tt = min(tsteps[i], 499)                      # CollaterV2: t==num_steps corrupts with Q_bar[t-1]
+        oh = tok.one_hot(toks[i])
+        torch.manual_seed(100 + i)
+        s, p = pu.sample_transition_matrix(oh, Qb[tt])
+        torch.manual_seed(100 + i)
+        e = torch.empty_like(p).exponential_(1)
+        assert torch.equal(torch.argmax(p / e, dim=1), s), "multinomial != argmax(p/E) on this torch build"
+        x_t.append(s); q_x.append(p); E.append(e)
+    x_t, q_x, E = torch.stack(x_t), torch.stack(q_x), torch.stack(E)
+
+    # --- LVB loss, single-sequence, n_tokens = 22 and 24 --------------------------------
+    src_oh = torch.stack([tok.one_hot(s) for s in x_t])
+    tgt_oh = torch.stack([tok.one_hot(s) for s in toks])
+    timestep = torch.tensor(tsteps, dtype=torch.long)
+    arrs = dict(x0=toks.numpy(), x_t=x_t.numpy(), q=q_x.numpy(), expo=E.numpy(), timestep=timestep.numpy(),
+                torch_version=np.array(torch.__version__))
+    for n_tok in (22, 24):
+        g = torch.Generator().manual_seed(200 + n_tok)
+        pred = (torch.randn(B, L, n_tok, generator=g) * 2).requires_grad_(True)
+        lf = pl.D3PMLVBLoss(tmax=500, tokenizer=tok, evaluation=True)
+        per = lf(src_oh, q_x, pred, toks, tgt_oh, timestep, Qt, Qb)
+        lf2 = pl.D3PMLVBLoss(tmax=500, tokenizer=tok)
+        lvb = lf2(src_oh, q_x, pred, toks, tgt_oh, timestep, Qt, Qb)
+        (gr,) = torch.autograd.grad(lvb, pred)
+        ce = torch.nn.CrossEntropyLoss(reduction="mean")(pred.reshape(-1, n_tok), toks.reshape(-1))
+        arrs.update({f"pred{n_tok}": pred.detach().numpy(), f"per_seq{n_tok}": per.detach().numpy(),
+                     f"lvb{n_tok}": lvb.detach().numpy(), f"grad{n_tok}": gr.numpy(), f"ce{n_tok}": ce.detach().numpy()})
+    save("protein_lvb_blat", **arrs)
+
+    # --- LVB loss, MSA variant -----------------------------------------------------------
+    g = torch.Generator().manual_seed(300)
+    Bm, D, Lm = 4, 3, 40
+    x0m = torch.randint(0, K, (Bm, D, Lm), generator=g)
+    tm = torch.tensor([1, 7, 333, 500], dtype=torch.long)
+    xtm, qm = [], []
+    for i in range(Bm):
+        oh = tok.one_hot(x0m[i]).flatten(0, 1)
+        p = torch.mm(oh, Qb[min(int(tm[i]), 499)])
+        e = torch.empty_like(p).exponential_(1, generator=g)
+        xtm.append(torch.argmax(p / e, dim=1).reshape(D, Lm)); qm.append(p.reshape(D, Lm, K))
+    xtm, qm = torch.stack(xtm), torch.stack(qm)
+    predm = (torch.randn(Bm, D, Lm, 24, generator=g) * 2).requires_grad_(True)
+    lfm = pl.D3PMLVBLossMSA(tmax=500, tokenizer=tok)
+    lvbm = lfm(tok.one_hot(xtm), qm, predm, x0m, tok.one_hot(x0m), tm, Qt, Qb)
+    (grm,) = torch.autograd.grad(lvbm, predm)
+    save("protein_lvb_msa", x0=x0m.numpy(), x_t=xtm.numpy(), q=qm.numpy(), timestep=tm.numpy(),
+         pred=predm.detach().numpy(), lvb=lvbm.detach().numpy(), grad=grm.numpy())
+
+    # --- full reverse sampling run with a toy denoiser, draws replayed -------------------
+    T, Bg, Lg = 20, 3, 48
+    Qb20, Qt20 = tok.q_uniform_schedule(num_steps=T, schedule="sohl-dickstein")
+    g = torch.Generator().manual_seed(400)
+    emb = torch.randn(K, 24, generator=g) * 1.5
+    tvec = torch.randn(T + 1, 24, generator=g) * 0.3
+
+    class Toy(torch.nn.Module):
+        def forward(self, x, tt):
+            return emb[x] + tvec[tt][:, None, :]
+
+    torch.manual_seed(401)
+    sample, strings = pg.generate_d3pm(Toy(), tok, Qt20, Qb20, T, Lg, "cpu", batch_size=Bg)
+    torch.manual_seed(401)
+    x_init = torch.randint(0, K, (Bg, Lg))
+    Es = torch.stack([torch.stack([torch.empty(Lg, K, dtype=torch.float64).exponential_(1) for _ in range(Bg)])
+                      for _ in range(T - 1)])
+    save("protein_generate", Q_bar=Qb20.numpy(), Q_t=Qt20.numpy(), emb=emb.numpy(), tvec=tvec.numpy(),
+         x_init=x_init.numpy(), expo=Es.numpy(), sample=sample.numpy(), strings=np.array(strings))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--part", choices=["image", "protein"], default=None)
+    a = ap.parse_args()
+    if a.part == "image":
+        part_image()
+    elif a.part == "protein":
+        part_protein()
+    else:
+        for part in ("image", "protein"):
+            subprocess.run([sys.executable, "-B", os.path.abspath(__file__), "--part", part], check=True)
+
+
+if __name__ == "__main__":
+    main()
