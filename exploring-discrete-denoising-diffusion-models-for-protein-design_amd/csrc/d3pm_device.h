@@ -1,0 +1,161 @@
+// Device-side helpers shared by the D3PM kernels (gfx950, wave64).
+//
+// Lane layout used everywhere: a token's K classes are spread over a group of
+// G consecutive lanes (G a power of two, 64/G tokens per wave); lane g of the
+// group owns V class slots.  In the vector layout (K == 4*G) slot v is class
+// 4*g+v and a lane's slots are one 16-byte access; in the strided layout slot
+// v is class g+G*v (any K <= G*V, slots past K masked).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/d3pm_hip.h"
+
+namespace d3pm {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define D3PM_CHECK_ARG(cond, ...)                    \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ::d3pm::set_error(__VA_ARGS__);                \
+      return D3PM_EINVAL;                            \
+    }                                                \
+  } while (0)
+
+#define D3PM_LAUNCH_CHECK(what)                                  \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) return ::d3pm::hip_fail(e__, what);   \
+  } while (0)
+
+// ---------------------------------------------------------------- DPP moves
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = dpp_mov<CTRL>((int)(b & 0xffffffffll));
+  int hi = dpp_mov<CTRL>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Exchange partner of step S (1,2,4,8 inside a 16-lane row by DPP; 16 and 32
+// through the LDS crossbar).  Steps 4 and 8 are mirrors, which pair lanes that
+// already hold equal partial results of the lower steps, so for a commutative
+// reduction they are as good as an xor butterfly.
+template <int S, typename T>
+__device__ __forceinline__ T partner(T v) {
+  if constexpr (S == 1) return dpp_mov<0xB1>(v);         // quad_perm [1,0,3,2]
+  else if constexpr (S == 2) return dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  else if constexpr (S == 4) return dpp_mov<0x141>(v);   // row_half_mirror
+  else if constexpr (S == 8) return dpp_mov<0x140>(v);   // row_mirror
+  else return __shfl_xor(v, S, 64);
+}
+
+template <int G, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+  if constexpr (G >= 2) v += partner<1>(v);
+  if constexpr (G >= 4) v += partner<2>(v);
+  if constexpr (G >= 8) v += partner<4>(v);
+  if constexpr (G >= 16) v += partner<8>(v);
+  if constexpr (G >= 32) v += partner<16>(v);
+  if constexpr (G >= 64) v += partner<32>(v);
+  return v;
+}
+template <int G, typename T>
+__device__ __forceinline__ T group_max(T v) {
+  if constexpr (G >= 2) v = fmax(v, partner<1>(v));
+  if constexpr (G >= 4) v = fmax(v, partner<2>(v));
+  if constexpr (G >= 8) v = fmax(v, partner<4>(v));
+  if constexpr (G >= 16) v = fmax(v, partner<8>(v));
+  if constexpr (G >= 32) v = fmax(v, partner<16>(v));
+  if constexpr (G >= 64) v = fmax(v, partner<32>(v));
+  return v;
+}
+
+// argmax with first-index tie-break (torch.argmax on CPU returns the first
+// maximal index).  Every lane of the group ends with the same (value, index).
+template <int S, typename T>
+__device__ __forceinline__ void argmax_step(T& v, int& i) {
+  T ov = partner<S>(v);
+  int oi = partner<S>(i);
+  bool take = (ov > v) || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+template <int G, typename T>
+__device__ __forceinline__ void group_argmax(T& v, int& i) {
+  if constexpr (G >= 2) argmax_step<1>(v, i);
+  if constexpr (G >= 4) argmax_step<2>(v, i);
+  if constexpr (G >= 8) argmax_step<4>(v, i);
+  if constexpr (G >= 16) argmax_step<8>(v, i);
+  if constexpr (G >= 32) argmax_step<16>(v, i);
+  if constexpr (G >= 64) argmax_step<32>(v, i);
+}
+
+// Sum over the whole wave, result valid in every lane.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
+
+// Block-wide sum of one value per thread; result valid in thread 0.
+// `scratch` holds one T per wave.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  T r = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) r += scratch[w];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------- tokens
+__device__ __forceinline__ int load_tok(const void* p, long idx, int bytes) {
+  return bytes == 8 ? (int)((const int64_t*)p)[idx] : ((const int32_t*)p)[idx];
+}
+
+// ---------------------------------------------------------------- Philox
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id, uint64_t seed) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32);
+  uint32_t c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+// U[0,1) with 24 random bits, like torch.rand for float32.
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }
+// U(0,1] with 53 random bits.
+__device__ __forceinline__ double u01d(uint32_t hi, uint32_t lo) {
+  uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
+  return ((double)m + 1.0) * 1.1102230246251565e-16;
+}
+
+// The reference's Gumbel transform (diffusion_discrete.py:283-284):
+// clip to [float32 tiny, 1], then -log(-log(u)).
+__device__ __forceinline__ float gumbel_from_uniform(float u) {
+  u = fminf(fmaxf(u, 1.17549435e-38f), 1.0f);
+  return -logf(-logf(u));
+}
+
+}  // namespace d3pm

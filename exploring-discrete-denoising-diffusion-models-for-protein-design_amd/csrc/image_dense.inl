@@ -1,0 +1,528 @@
+// Image-style D3PM kernels on dense float32 tables (Gaussian and banded
+// transitions): row gathers for the factors that depend on integer tokens and a
+// K x K contraction of the predicted x0 distribution against Qbar_{t-1}.
+// Included by image_structured.hip (same translation unit, namespace d3pm).
+//
+// The contraction kernels work on tiles of TM tokens of one batch element: the
+// tile's softmax rows sit in LDS, each thread owns one output class for TPT
+// tokens and streams its column of Qbar_{t-1} once per tile (coalesced across
+// the workgroup, L2-resident across tiles of the same timestep).
+
+namespace d3pm {
+
+constexpr int next_pow2_c(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <class L>
+struct DenseCfg {
+  static constexpr int TPP = BLOCK / L::G;              // tokens per epilogue pass
+  static constexpr int TM = TPP > 16 ? TPP : 16;        // tokens per tile
+  static constexpr int KC = next_pow2_c(L::G * L::V);   // threads per token group in the contraction
+  static constexpr int CG = BLOCK / KC;                 // token groups
+  static constexpr int TPT = TM / CG;                   // tokens per thread
+  static_assert(TM % CG == 0 && TPT >= 1, "tile does not split over the workgroup");
+};
+
+// ------------------------------------------------------------------ gathers only
+template <class L>
+__global__ __launch_bounds__(BLOCK) void k_dense_q_probs(ImgArgs a, float* __restrict__ out) {
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    float r[L::V];
+    load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, r);
+    store_slots<L>(out + n * K, g, K, r);
+  }
+}
+
+template <class L, int NOISE>
+__global__ __launch_bounds__(BLOCK) void k_dense_q_sample(ImgArgs a, const float* __restrict__ noise, uint64_t seed,
+                                                          uint64_t offset, int64_t* __restrict__ out) {
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    float p[L::V], u[L::V];
+    load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, p);
+    if constexpr (NOISE == D3PM_NOISE_PHILOX) {
+      const U4 r = philox4x32_10((uint64_t)n * L::G + g, offset, seed);
+      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) u[v] = u01(rr[v]);
+    } else {
+      load_slots<L>(noise + n * K, g, K, 0.5f, u);
+    }
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]);
+      const float val = logf(p[v] + eps) + gum;
+      if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+    }
+    group_argmax<L::G>(best, besti);
+    if (g == 0) out[n] = besti;
+  }
+}
+
+template <class L>
+__global__ __launch_bounds__(BLOCK) void k_dense_posterior_tokens(ImgArgs a, float* __restrict__ out) {
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const float log_one = (float)log((double)(1.0f + eps)), log_zero = (float)log((double)eps);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int xt = load_tok(a.xt, n, a.xt_bytes);
+    float r[L::V];
+    if (t == 0) {
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) r[v] = (L::cls(g, v) == x0) ? log_one : log_zero;
+    } else {
+      float f1[L::V], f2[L::V];
+      load_slots<L>(a.tb.qoneT + ((size_t)t * K + xt) * K, g, K, 0.0f, f1);
+      load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + x0) * K, g, K, 0.0f, f2);
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) r[v] = logf(f1[v] + eps) + logf(f2[v] + eps);
+    }
+    store_slots<L>(out + n * K, g, K, r);
+  }
+}
+
+template <class L>
+__global__ __launch_bounds__(BLOCK) void k_dense_prior(ImgArgs a, int absorbing, float* __restrict__ part) {
+  __shared__ float red[BLOCK / 64];
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = a.tb.T - 1;
+  const float lp_uniform = logf(1.0f / (float)K + eps);
+  const float lp_one = logf(1.0f + eps), lp_zero = logf(eps);
+  float acc = 0;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    float p[L::V];
+    load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, p);
+    float kl = 0;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      const float lprior = absorbing ? (c == K / 2 ? lp_one : lp_zero) : lp_uniform;
+      kl += (c < K) ? p[v] * (logf(p[v] + eps) - lprior) : 0.0f;
+    }
+    kl = group_sum<L::G>(kl);
+    if (g == 0) acc += kl;
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)b * a.chunks + chunk) * 2 + 0] = s;
+    part[((size_t)b * a.chunks + chunk) * 2 + 1] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ tile kernel
+// out[tok][j] = sum_i in[tok][i] * M[i][j] for the TM tokens of a tile; `in` and
+// `out` are LDS [TM][K]; M is a global [K][K] float32 matrix.
+template <class L>
+__device__ __forceinline__ void tile_contract(const float* __restrict__ M, int K, const float* in, float* out) {
+  using C = DenseCfg<L>;
+  const int j = threadIdx.x % C::KC, tg = threadIdx.x / C::KC;
+  float acc[C::TPT];
+#pragma unroll
+  for (int q = 0; q < C::TPT; ++q) acc[q] = 0.0f;
+  if (j < K) {
+    const float* col = M + j;
+    const float* rows = in + (size_t)tg * C::TPT * K;
+#pragma unroll 4
+    for (int i = 0; i < K; ++i) {
+      const float m = col[(size_t)i * K];
+#pragma unroll
+      for (int q = 0; q < C::TPT; ++q) acc[q] = fmaf(rows[q * K + i], m, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < C::TPT; ++q) out[(size_t)(tg * C::TPT + q) * K + j] = acc[q];
+  }
+}
+
+enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
+
+struct DenseExtra {
+  const float* logits; long ld;
+  // loss
+  int loss_type; float hybrid_coeff; float grad_scale; const float* grad_out; float* part; float* dlogits;
+  // posterior logits out / probs out
+  float* out; float* probs;
+  // sampling
+  const float* noise; uint64_t seed, offset; int64_t* sample;
+};
+
+template <class L, int MODE, bool GRAD, int NOISE>
+__global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
+  using C = DenseCfg<L>;
+  extern __shared__ float lds[];
+  __shared__ float red[2 * (BLOCK / 64)];
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  float* s_pi = lds;                       // [TM][K] softmax(z)
+  float* s_f2 = lds + (size_t)C::TM * K;   // [TM][K] pi @ Qm, later d loss / d f2
+  float* s_gp = s_f2 + (size_t)C::TM * K;  // [TM][K] d loss / d pi (GRAD only)
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const bool need_post = (t > 0) && !(MODE == DENSE_LOSS && e.loss_type == D3PM_LOSS_CE);
+  const float* Qm = need_post ? a.tb.qbar + (size_t)(t - 1) * K * K : nullptr;
+  const float* QmT = (need_post && GRAD) ? a.tb.qbarT + (size_t)(t - 1) * K * K : nullptr;
+
+  float w_vb = 0, w_ce = 0;
+  if constexpr (MODE == DENSE_LOSS) {
+    const float gb = e.grad_scale * ((GRAD && e.grad_out) ? e.grad_out[b] : 1.0f);
+    const float cnorm = gb / ((float)a.npos * LN2);
+    w_vb = (e.loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
+    w_ce = (e.loss_type == D3PM_LOSS_KL) ? 0.0f : (e.loss_type == D3PM_LOSS_CE ? cnorm : e.hybrid_coeff * cnorm);
+  }
+  float acc_vb = 0, acc_ce = 0;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += C::TM) {
+    // ---- phase 1: softmax of the tile's logits into LDS, CE term
+    float zkeep[C::TM / C::TPP][L::V];   // logits of this lane's tokens (only used at t == 0 / POST)
+    float cekeep[C::TM / C::TPP];
+#pragma unroll
+    for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+      const int tok = ps * C::TPP + slot;
+      const long pos = tile0 + tok;
+      float z[L::V], pi[L::V], zmax = 0, zsum = 1;
+      const bool live = pos < p1;
+      const long n = (long)b * a.npos + (live ? pos : tile0);
+      load_slots<L>(e.logits + n * e.ld, g, K, -INFINITY, z);
+      group_softmax<L>(z, pi, zmax, zsum);
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        zkeep[ps][v] = z[v];
+        const int c = L::cls(g, v);
+        if (c < K) s_pi[(size_t)tok * K + c] = live ? pi[v] : 0.0f;
+      }
+      cekeep[ps] = 0;
+      if constexpr (MODE == DENSE_LOSS) {
+        const int x0 = load_tok(a.x0, n, a.x0_bytes);
+        float zx0 = 0;
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0) ? z[v] : 0.0f;
+        zx0 = group_sum<L::G>(zx0);
+        cekeep[ps] = (zmax + logf(zsum)) - zx0;
+      }
+      if constexpr (MODE == DENSE_SAMPLE) {
+        if (e.probs && live) store_slots<L>(e.probs + n * K, g, K, pi);
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: f2 = pi @ Qbar_{t-1}
+    if (need_post) tile_contract<L>(Qm, K, s_pi, s_f2);
+    __syncthreads();
+    // ---- phase 3: per-token epilogue
+#pragma unroll
+    for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+      const int tok = ps * C::TPP + slot;
+      const long pos = tile0 + tok;
+      const bool live = pos < p1;
+      const long n = (long)b * a.npos + (live ? pos : tile0);
+      const int xt = load_tok(a.xt, n, a.xt_bytes);
+      float f1[L::V], lm[L::V], f2e[L::V];
+      if (need_post) {
+        load_slots<L>(a.tb.qoneT + ((size_t)t * K + xt) * K, g, K, 0.0f, f1);
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          const int c = L::cls(g, v);
+          f2e[v] = (c < K ? s_f2[(size_t)tok * K + c] : 1.0f) + eps;
+          lm[v] = logf(f1[v] + eps) + logf(f2e[v]);
+        }
+      }
+      if constexpr (MODE == DENSE_POST) {
+        float r[L::V];
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps][v] : lm[v];
+        if (live) store_slots<L>(e.out + n * K, g, K, r);
+      } else if constexpr (MODE == DENSE_SAMPLE) {
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        float u[L::V];
+        if (t > 0) {
+          if constexpr (NOISE == D3PM_NOISE_PHILOX) {
+            const U4 r = philox4x32_10((uint64_t)n * L::G + g, e.offset, e.seed);
+            const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int v = 0; v < L::V; ++v) u[v] = u01(rr[v]);
+          } else {
+            load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          const int c = L::cls(g, v);
+          float val;
+          if (t == 0) val = zkeep[ps][v];
+          else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]));
+          if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+        }
+        group_argmax<L::G>(best, besti);
+        if (g == 0 && live) e.sample[n] = besti;
+      } else {  // DENSE_LOSS
+        const int x0 = load_tok(a.x0, n, a.x0_bytes);
+        const float ce = cekeep[ps];
+        float vb = ce;
+        if (need_post) {
+          float f2t[L::V], tl[L::V];
+          load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + x0) * K, g, K, 0.0f, f2t);
+          float mmax = -INFINITY, tmax = -INFINITY;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const bool ok = L::cls(g, v) < K;
+            lm[v] = ok ? lm[v] + eps : -INFINITY;
+            tl[v] = ok ? (logf(f1[v] + eps) + logf(f2t[v] + eps)) + eps : -INFINITY;
+            mmax = fmaxf(mmax, lm[v]);
+            tmax = fmaxf(tmax, tl[v]);
+          }
+          mmax = group_max<L::G>(mmax);
+          tmax = group_max<L::G>(tmax);
+          float em[L::V], et[L::V], sm = 0, st = 0;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            em[v] = expf(lm[v] - mmax); sm += em[v];
+            et[v] = expf(tl[v] - tmax); st += et[v];
+          }
+          sm = group_sum<L::G>(sm);
+          st = group_sum<L::G>(st);
+          const float lsm_off = mmax + logf(sm), lst_off = tmax + logf(st);
+          const float ism = 1.0f / sm, ist = 1.0f / st;
+          float kl = 0;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const bool ok = L::cls(g, v) < K;
+            kl += ok ? (et[v] * ist) * ((tl[v] - lst_off) - (lm[v] - lsm_off)) : 0.0f;
+          }
+          vb = group_sum<L::G>(kl);
+          if constexpr (GRAD) {
+#pragma unroll
+            for (int v = 0; v < L::V; ++v) {
+              const int c = L::cls(g, v);
+              const float gm = (em[v] * ism - et[v] * ist) * w_vb;
+              if (c < K) s_f2[(size_t)tok * K + c] = live ? gm / f2e[v] : 0.0f;
+            }
+          }
+        }
+        if (g == 0 && live) { acc_vb += vb; acc_ce += ce; }
+      }
+    }
+    if constexpr (MODE == DENSE_LOSS && GRAD) {
+      __syncthreads();
+      // ---- phase 4: d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T
+      if (need_post) tile_contract<L>(QmT, K, s_f2, s_gp);
+      __syncthreads();
+      // ---- phase 5: through the softmax of z, plus the CE term
+#pragma unroll
+      for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+        const int tok = ps * C::TPP + slot;
+        const long pos = tile0 + tok;
+        if (pos >= p1) continue;     // whole lane groups leave together
+        const long n = (long)b * a.npos + pos;
+        const int x0 = load_tok(a.x0, n, a.x0_bytes);
+        float pi[L::V], gz[L::V];
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          const int c = L::cls(g, v);
+          pi[v] = c < K ? s_pi[(size_t)tok * K + c] : 0.0f;
+        }
+        if (need_post) {
+          float gp[L::V], dot = 0;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            gp[v] = c < K ? s_gp[(size_t)tok * K + c] : 0.0f;
+            dot += pi[v] * gp[v];
+          }
+          dot = group_sum<L::G>(dot);
+#pragma unroll
+          for (int v = 0; v < L::V; ++v)
+            gz[v] = pi[v] * (gp[v] - dot) + w_ce * (pi[v] - ((L::cls(g, v) == x0) ? 1.0f : 0.0f));
+        } else {
+          const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) gz[v] = w * (pi[v] - ((L::cls(g, v) == x0) ? 1.0f : 0.0f));
+        }
+        store_slots<L>(e.dlogits + n * e.ld, g, K, gz);
+        if (!L::VEC && e.ld > K) zero_tail<L>(e.dlogits + n * e.ld, g, K, e.ld);
+      }
+    }
+    __syncthreads();   // LDS tiles are reused by the next tile
+  }
+  if constexpr (MODE == DENSE_LOSS) {
+    acc_vb = wave_sum(acc_vb);
+    acc_ce = wave_sum(acc_ce);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float svb = 0, sce = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
+      e.part[((size_t)b * a.chunks + chunk) * 2 + 0] = svb;
+      e.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <class L>
+static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0b, const void* xt, int xtb, const void* t,
+                               int tb_, int B, long npos) {
+  ImgArgs a = make_args(tb, x0, x0b, xt, xtb, t, tb_, B, npos, L::G);
+  const TokenGrid tg = token_grid(B, npos, DenseCfg<L>::TM);
+  a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
+  return a;
+}
+
+static int dense_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes, int B,
+                         long npos, float* out, hipStream_t s) {
+  return dispatch_layout(tb->K, aligned16(out) && aligned16(tb->qbar), [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);
+    hipLaunchKernelGGL(k_dense_q_probs<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, out);
+    D3PM_LAUNCH_CHECK("k_dense_q_probs");
+    return D3PM_OK;
+  });
+}
+
+static int dense_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes, int B,
+                          long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset, int64_t* x_t,
+                          hipStream_t s) {
+  const bool vec = aligned16(tb->qbar) && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise));
+  return dispatch_layout(tb->K, vec, [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);
+    const dim3 grid(B * a.chunks), block(BLOCK);
+    if (noise_kind == D3PM_NOISE_UNIFORM)
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, noise, seed, offset, x_t);
+    else if (noise_kind == D3PM_NOISE_GUMBEL)
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, noise, seed, offset, x_t);
+    else
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, noise, seed, offset, x_t);
+    D3PM_LAUNCH_CHECK("k_dense_q_sample");
+    return D3PM_OK;
+  });
+}
+
+template <class L>
+static size_t dense_lds_bytes(int K, bool grad) {
+  return (size_t)DenseCfg<L>::TM * K * sizeof(float) * (grad ? 3 : 2);
+}
+
+static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start, int x_start_is_logits, long ld,
+                                  int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes, int B,
+                                  long npos, float* out, hipStream_t s) {
+  const bool vec = aligned16(out) && aligned16(tb->qbar) && aligned16(tb->qoneT) &&
+                   (!x_start_is_logits || (aligned16(x_start) && ld == tb->K));
+  return dispatch_layout(tb->K, vec, [&](auto lay) {
+    using L = decltype(lay);
+    if (!x_start_is_logits) {
+      ImgArgs a = make_args(tb, x_start, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, L::G);
+      hipLaunchKernelGGL(k_dense_posterior_tokens<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, out);
+      D3PM_LAUNCH_CHECK("k_dense_posterior_tokens");
+      return D3PM_OK;
+    }
+    ImgArgs a = make_dense_args<L>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
+    DenseExtra e{};
+    e.logits = (const float*)x_start; e.ld = ld; e.out = out;
+    hipLaunchKernelGGL((k_dense_tile<L, DENSE_POST, false, D3PM_NOISE_GUMBEL>), dim3(B * a.chunks), dim3(BLOCK),
+                       dense_lds_bytes<L>(tb->K, false), s, a, e);
+    D3PM_LAUNCH_CHECK("k_dense_tile<POST>");
+    return D3PM_OK;
+  });
+}
+
+static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
+                             const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos, int loss_type,
+                             float hybrid_coeff, float grad_scale, const float* grad_out, float* vb, float* ce,
+                             float* loss,
+                             float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  D3PM_CHECK_ARG(!dlogits || tb->qbarT, "dense backward needs the transposed cumulative table (qbarT)");
+  const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits)) && aligned16(tb->qbar) &&
+                   aligned16(tb->qoneT);
+  return dispatch_layout(tb->K, vec, [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_dense_args<L>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
+    const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    DenseExtra e{};
+    e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale; e.grad_out = grad_out;
+    e.part = (float*)workspace; e.dlogits = dlogits;
+    const dim3 grid(B * a.chunks), block(BLOCK);
+    if (dlogits)
+      hipLaunchKernelGGL((k_dense_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL>), grid, block,
+                         dense_lds_bytes<L>(tb->K, true), s, a, e);
+    else
+      hipLaunchKernelGGL((k_dense_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL>), grid, block,
+                         dense_lds_bytes<L>(tb->K, false), s, a, e);
+    D3PM_LAUNCH_CHECK("k_dense_tile<LOSS>");
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, e.part, B, a.chunks, npos, loss_type,
+                       hybrid_coeff, vb, ce, loss);
+    D3PM_LAUNCH_CHECK("k_loss_finalize");
+    return D3PM_OK;
+  });
+}
+
+static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x_t, int xt_bytes,
+                          const void* t, int t_bytes, int B, long npos, const float* noise, int noise_kind,
+                          uint64_t seed, uint64_t offset, int64_t* sample, float* probs, hipStream_t s) {
+  const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
+                   (!probs || aligned16(probs)) && aligned16(tb->qbar) && aligned16(tb->qoneT);
+  return dispatch_layout(tb->K, vec, [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_dense_args<L>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
+    DenseExtra e{};
+    e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.sample = sample; e.probs = probs;
+    const dim3 grid(B * a.chunks), block(BLOCK);
+    const size_t sh = dense_lds_bytes<L>(tb->K, false);
+    if (noise_kind == D3PM_NOISE_UNIFORM)
+      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_UNIFORM>), grid, block, sh, s, a, e);
+    else if (noise_kind == D3PM_NOISE_GUMBEL)
+      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_GUMBEL>), grid, block, sh, s, a, e);
+    else
+      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_PHILOX>), grid, block, sh, s, a, e);
+    D3PM_LAUNCH_CHECK("k_dense_tile<SAMPLE>");
+    return D3PM_OK;
+  });
+}
+
+static int dense_prior(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos, int absorbing,
+                       float* out, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  return dispatch_layout(tb->K, aligned16(tb->qbar), [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, nullptr, 8, B, npos, L::G);
+    const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(k_dense_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
+    D3PM_LAUNCH_CHECK("k_dense_prior");
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, D3PM_LOSS_KL,
+                       0.0f, out, (float*)nullptr, (float*)nullptr);
+    D3PM_LAUNCH_CHECK("k_loss_finalize");
+    return D3PM_OK;
+  });
+}
+
+}  // namespace d3pm

@@ -1,0 +1,105 @@
+// Lane layouts for [N, K] row-major class tensors and the host-side choice
+// between them.  See d3pm_device.h for the convention.
+#pragma once
+#include "d3pm_device.h"
+
+namespace d3pm {
+
+template <int G_, int V_, bool VEC_>
+struct Layout {
+  static constexpr int G = G_;        // lanes per token
+  static constexpr int V = V_;        // class slots per lane
+  static constexpr bool VEC = VEC_;   // slots contiguous (one 16-byte access)
+  static constexpr int TOKENS_PER_WAVE = 64 / G_;
+  __device__ static __forceinline__ int cls(int g, int v) { return VEC_ ? 4 * g + v : g + G_ * v; }
+};
+
+// Load one token's slots of a float row; masked slots read `fill`.
+template <class L>
+__device__ __forceinline__ void load_slots(const float* __restrict__ row, int g, int K, float fill, float (&z)[L::V]) {
+  if constexpr (L::VEC) {
+    const float4 q = *reinterpret_cast<const float4*>(row + 4 * g);
+    z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+  } else {
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      z[v] = c < K ? row[c] : fill;
+    }
+  }
+}
+template <class L>
+__device__ __forceinline__ void load_slots(const double* __restrict__ row, int g, int K, double fill, double (&z)[L::V]) {
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) {
+    const int c = L::cls(g, v);
+    z[v] = c < K ? row[c] : fill;
+  }
+}
+
+template <class L>
+__device__ __forceinline__ void store_slots(float* __restrict__ row, int g, int K, const float (&z)[L::V]) {
+  if constexpr (L::VEC) {
+    *reinterpret_cast<float4*>(row + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      if (c < K) row[c] = z[v];
+    }
+  }
+}
+
+// Zero the padding columns [K, ld) of a row (rows wider than K only occur in
+// the strided layout).
+template <class L>
+__device__ __forceinline__ void zero_tail(float* __restrict__ row, int g, int K, long ld) {
+  for (long c = K + g; c < ld; c += L::G) row[c] = 0.0f;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Calls f(Layout<...>{}) for the layout that fits K.  `vec_ok` says whether
+// every float row the kernel touches is 16-byte aligned with stride K.
+template <class F>
+int dispatch_layout(int K, bool vec_ok, F&& f) {
+  if (vec_ok) {
+    switch (K) {
+      case 16: return f(Layout<4, 4, true>{});
+      case 32: return f(Layout<8, 4, true>{});
+      case 64: return f(Layout<16, 4, true>{});
+      case 128: return f(Layout<32, 4, true>{});
+      case 256: return f(Layout<64, 4, true>{});
+      default: break;
+    }
+  }
+  if (K <= 8) return f(Layout<2, 4, false>{});
+  if (K <= 24) return f(Layout<8, 3, false>{});
+  if (K <= 32) return f(Layout<8, 4, false>{});
+  if (K <= 64) return f(Layout<16, 4, false>{});
+  if (K <= 128) return f(Layout<32, 4, false>{});
+  if (K <= 256) return f(Layout<64, 4, false>{});
+  set_error("K = %d is not supported (2 <= K <= 256)", K);
+  return D3PM_EUNSUPPORTED;
+}
+
+// Grid for kernels that walk [B, npos] tokens with one batch element per
+// blockIdx.y: enough workgroups to fill 256 CUs several times over, whole
+// passes of `tokens_per_pass` per workgroup.
+struct TokenGrid {
+  int chunks;        // gridDim.x
+  long chunk_pos;    // positions per chunk (multiple of tokens_per_pass)
+};
+inline TokenGrid token_grid(int B, long npos, int tokens_per_pass, int target_blocks = 2048) {
+  long passes = (npos + tokens_per_pass - 1) / tokens_per_pass;
+  long want = (target_blocks + B - 1) / B;
+  if (want < 1) want = 1;
+  long chunks = passes < want ? passes : want;
+  if (chunks < 1) chunks = 1;
+  long ppc = (passes + chunks - 1) / chunks;
+  chunks = (passes + ppc - 1) / ppc;
+  if (chunks < 1) chunks = 1;
+  return TokenGrid{(int)chunks, ppc * tokens_per_pass};
+}
+
+}  // namespace d3pm

@@ -1,0 +1,363 @@
+// Protein-style (EvoDiff-like) D3PM kernels: batched forward corruption, the LVB
+// loss with its gradient, and the reverse step.  Arithmetic after the float32
+// softmax is float64, as in protein_generation/losses.py:65 and
+// generate.py:30.  Tables are column-structured digests (uniform schedule):
+// entry(i,j) = i==j ? diag[j] : off[j], which turns the reference's [L,K,K]
+// temporaries into O(K) work per token:
+//   s_j = sum_i p_i^2 Qm[i,j] = off_j * (S2 - p_j^2) + diag_j * p_j^2.
+#include "layout.h"
+
+namespace d3pm {
+
+constexpr int PBLOCK = 256;
+
+struct ProtArgs {
+  d3pm_tables_f64 tb;
+  const int64_t* x0;
+  const int64_t* xt;
+  const int64_t* t;
+  int B; long npos;
+  int chunks; long chunk_pos;
+};
+
+__device__ __forceinline__ const double* dgd(const double* digest, int t, int c, int K) {
+  return digest + ((size_t)t * 2 + c) * K;
+}
+
+template <class L>
+__device__ __forceinline__ void load_digest_d(const double* digest, int t, int c, int K, int g, double (&out)[L::V]) {
+  load_slots<L>(dgd(digest, t, c, K), g, K, 0.0, out);
+}
+
+// Exp(1) draws for one lane's slots: passed in, or Philox.
+template <class L>
+__device__ __forceinline__ void load_expo(const double* expo, long n, int K, int g, uint64_t seed, uint64_t offset,
+                                          double (&e)[L::V]) {
+  if (expo) {
+    load_slots<L>(expo + n * K, g, K, 1.0, e);
+  } else {
+    static_assert(L::V <= 4, "two Philox calls cover four slots");
+    const U4 r0 = philox4x32_10(((uint64_t)n * L::G + g) * 2, offset, seed);
+    const U4 r1 = philox4x32_10(((uint64_t)n * L::G + g) * 2 + 1, offset, seed);
+    const double u[4] = {u01d(r0.x, r0.y), u01d(r0.z, r0.w), u01d(r1.x, r1.y), u01d(r1.z, r1.w)};
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) e[v] = -log(u[v]);
+  }
+}
+
+// ------------------------------------------------------------------ forward corruption
+template <class L>
+__global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __restrict__ expo, uint64_t seed,
+                                                    uint64_t offset, int64_t* __restrict__ x_t,
+                                                    double* __restrict__ probs) {
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = (int)a.t[b];
+  double d[L::V], o[L::V];
+  load_digest_d<L>(a.tb.qbar_digest, t, 0, K, g, d);
+  load_digest_d<L>(a.tb.qbar_digest, t, 1, K, g, o);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = (int)a.x0[n];
+    double e[L::V];
+    load_expo<L>(expo, n, K, g, seed, offset, e);
+    double best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      const double p = (c == x0) ? d[v] : o[v];
+      if (probs && c < K) probs[n * K + c] = p;
+      const double val = p / e[v];
+      if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+    }
+    group_argmax<L::G>(best, besti);
+    if (g == 0) x_t[n] = besti;
+  }
+}
+
+// ------------------------------------------------------------------ shared maths
+// float32 softmax over the first K logits, promoted to float64.
+template <class L>
+__device__ __forceinline__ void softmax_f32_to_f64(const float (&z)[L::V], int g, int K, double (&p)[L::V]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) m = fmaxf(m, (L::cls(g, v) < K) ? z[v] : -INFINITY);
+  m = group_max<L::G>(m);
+  float e[L::V], s = 0;
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) {
+    e[v] = (L::cls(g, v) < K) ? expf(z[v] - m) : 0.0f;
+    s += e[v];
+  }
+  s = group_sum<L::G>(s);
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) p[v] = (double)(e[v] / s);
+}
+
+// r_j = A_j * s_j (unnormalised p-squared marginal) and its sum over j.
+template <class L>
+__device__ __forceinline__ void marginal(const double (&p)[L::V], const double (&md)[L::V], const double (&mo)[L::V],
+                                         double a_diag, double a_off, int xt, int g, int K, double (&A)[L::V],
+                                         double (&r)[L::V], double& rsum) {
+  double s2 = 0;
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) s2 += p[v] * p[v];
+  s2 = group_sum<L::G>(s2);
+  double rs = 0;
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) {
+    const int c = L::cls(g, v);
+    const double pp = p[v] * p[v];
+    A[v] = (c == xt) ? a_diag : a_off;
+    r[v] = (c < K) ? A[v] * (mo[v] * (s2 - pp) + md[v] * pp) : 0.0;
+    rs += r[v];
+  }
+  rsum = group_sum<L::G>(rs);
+}
+
+// ------------------------------------------------------------------ LVB loss
+template <class L, bool GRAD>
+__global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __restrict__ pred, long ld,
+                                                     const double* __restrict__ q, int tmax, int msa, double grad_scale,
+                                                     double log_prior, double* __restrict__ part,
+                                                     float* __restrict__ dpred) {
+  __shared__ double red[PBLOCK / 64];
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = (int)a.t[b];
+  const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
+  double md[L::V], mo[L::V];
+  if (branch == 2) {
+    load_digest_d<L>(a.tb.qbar_digest, t - 1, 0, K, g, md);
+    load_digest_d<L>(a.tb.qbar_digest, t - 1, 1, K, g, mo);
+  }
+  const double cscale = grad_scale / (double)a.npos;
+  double acc = 0;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = (int)a.x0[n];
+    float z[L::V];
+    float gz[L::V];
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) gz[v] = 0.0f;
+    double tok_loss = 0;
+    if (branch == 0) {
+      // CrossEntropyLoss over all ld logits (losses.py:54), float32
+      load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
+      float m = -INFINITY;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) m = fmaxf(m, z[v]);
+      m = group_max<L::G>(m);
+      float e[L::V], s = 0, zx0 = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        e[v] = expf(z[v] - m); s += e[v];
+        zx0 += (L::cls(g, v) == x0) ? z[v] : 0.0f;
+      }
+      s = group_sum<L::G>(s);
+      zx0 = group_sum<L::G>(zx0);
+      tok_loss = (double)((m + logf(s)) - zx0);
+      if constexpr (GRAD) {
+#pragma unroll
+        for (int v = 0; v < L::V; ++v)
+          gz[v] = (float)(cscale * (double)(e[v] / s - ((L::cls(g, v) == x0) ? 1.0f : 0.0f)));
+      }
+    } else if (branch == 1) {
+      // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60)
+      double qq[L::V];
+      load_slots<L>(q + n * K, g, K, 0.0, qq);
+      double s = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) s += (qq[v] > 0.0 ? qq[v] * log(qq[v]) : 0.0) - qq[v] * log_prior;
+      // 'batchmean' divides by the leading size of q[i]: L for a sequence (what the
+      // finalize step does), but only the depth D for an MSA laid out [D,L,K]
+      tok_loss = group_sum<L::G>(s) * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
+    } else {
+      const int xt = (int)a.xt[n];
+      load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
+      double p[L::V], A[L::V], r[L::V], rsum;
+      softmax_f32_to_f64<L>(z, g, K, p);
+      const double a_diag = dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = dgd(a.tb.qone_digest, t, 1, K)[xt];
+      marginal<L>(p, md, mo, a_diag, a_off, xt, g, K, A, r, rsum);
+      // denominator Qbar_t[x0, x_t] (MSA variant: Qbar_{t-1}[x0, x_t], losses.py:148)
+      const int td = msa ? t - 1 : t;
+      const double den = dgd(a.tb.qbar_digest, td, (x0 == xt) ? 0 : 1, K)[xt];
+      double post[L::V], s = 0, psum = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const int c = L::cls(g, v);
+        post[v] = (c < K) ? A[v] * ((c == x0) ? md[v] : mo[v]) / den : 0.0;
+        psum += post[v];
+        if (c < K) s += (post[v] > 0.0 ? post[v] * log(post[v]) : 0.0) - post[v] * log(r[v] / rsum);
+      }
+      tok_loss = group_sum<L::G>(s);
+      if constexpr (GRAD) {
+        psum = group_sum<L::G>(psum);
+        double gs[L::V], W = 0;
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          const bool ok = L::cls(g, v) < K;
+          const double gr = ok ? (-post[v] / r[v] + psum / rsum) * cscale : 0.0;
+          gs[v] = gr * A[v];
+          W += gs[v] * mo[v];
+        }
+        W = group_sum<L::G>(W);
+        double gp[L::V], dot = 0;
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          gp[v] = 2.0 * p[v] * (W + gs[v] * (md[v] - mo[v]));
+          dot += p[v] * gp[v];
+        }
+        dot = group_sum<L::G>(dot);
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) gz[v] = (L::cls(g, v) < K) ? (float)(p[v] * (gp[v] - dot)) : 0.0f;
+      }
+    }
+    if constexpr (GRAD) store_slots<L>(dpred + n * ld, g, (int)ld, gz);
+    if (g == 0) acc += tok_loss;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[(size_t)b * a.chunks + chunk] = s;
+}
+
+__global__ void k_lvb_finalize(const double* __restrict__ part, int B, int chunks, long npos,
+                               double* __restrict__ per_seq) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)b * chunks + c];
+  per_seq[b] = s / (double)npos;
+}
+
+// ------------------------------------------------------------------ reverse step
+template <class L>
+__global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float* __restrict__ pred, long ld,
+                                                        const double* __restrict__ expo, uint64_t seed, uint64_t offset,
+                                                        int64_t* __restrict__ out) {
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = (int)a.t[b];
+  double md[L::V], mo[L::V];
+  load_digest_d<L>(a.tb.qbar_digest, t - 1, 0, K, g, md);
+  load_digest_d<L>(a.tb.qbar_digest, t - 1, 1, K, g, mo);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    const int xt = (int)a.xt[n];
+    float z[L::V];
+    load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
+    double p[L::V], A[L::V], r[L::V], rsum, e[L::V];
+    softmax_f32_to_f64<L>(z, g, K, p);
+    const double a_diag = dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = dgd(a.tb.qone_digest, t, 1, K)[xt];
+    marginal<L>(p, md, mo, a_diag, a_off, xt, g, K, A, r, rsum);
+    load_expo<L>(expo, n, K, g, seed, offset, e);
+    double best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      const double val = (r[v] / rsum) / e[v];
+      if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+    }
+    group_argmax<L::G>(best, besti);
+    if (g == 0) out[n] = besti;
+  }
+}
+
+static int check_prot(const d3pm_tables_f64* tb, int B, long npos) {
+  D3PM_CHECK_ARG(tb && tb->qbar_digest && tb->qone_digest, "tables descriptor or digest is null");
+  D3PM_CHECK_ARG(tb->K >= 2 && tb->K <= 256 && tb->T >= 1, "need 2 <= K <= 256, T >= 1 (K=%d, T=%d)", tb->K, tb->T);
+  D3PM_CHECK_ARG(B >= 0 && npos >= 0, "negative batch or position count");
+  return D3PM_OK;
+}
+
+static ProtArgs make_prot(const d3pm_tables_f64* tb, const int64_t* x0, const int64_t* xt, const int64_t* t, int B,
+                          long npos, int G) {
+  ProtArgs a;
+  a.tb = *tb; a.x0 = x0; a.xt = xt; a.t = t; a.B = B; a.npos = npos;
+  const TokenGrid tg = token_grid(B, npos, PBLOCK / G);
+  a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
+  return a;
+}
+
+}  // namespace d3pm
+
+using namespace d3pm;
+
+extern "C" int d3pm_corrupt(const d3pm_tables_f64* tb, const int64_t* x0, const int64_t* t, int B, long npos,
+                            const double* expo, uint64_t seed, uint64_t offset, int64_t* x_t, double* probs,
+                            void* stream) {
+  if (int rc = check_prot(tb, B, npos)) return rc;
+  if (B == 0 || npos == 0) return D3PM_OK;
+  D3PM_CHECK_ARG(x0 && t && x_t, "null pointer");
+  return dispatch_layout(tb->K, false, [&](auto lay) {
+    using L = decltype(lay);
+    ProtArgs a = make_prot(tb, x0, nullptr, t, B, npos, L::G);
+    hipLaunchKernelGGL(k_corrupt<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, expo, seed, offset,
+                       x_t, probs);
+    D3PM_LAUNCH_CHECK("k_corrupt");
+    return D3PM_OK;
+  });
+}
+
+extern "C" size_t d3pm_lvb_loss_workspace(int B, long npos, int K) {
+  (void)K;
+  long passes = npos > 0 ? npos : 1;
+  long chunks = passes < 4096 ? passes : 4096;
+  return (size_t)(B > 0 ? B : 1) * (size_t)chunks * sizeof(double);
+}
+
+extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                             const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax, int msa,
+                             double grad_scale, double* per_seq, float* dpred, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (int rc = check_prot(tb, B, npos)) return rc;
+  D3PM_CHECK_ARG(ld >= tb->K && ld <= 256, "row stride (n_tokens) must be in [K, 256], got %ld", ld);
+  if (B == 0) return D3PM_OK;
+  D3PM_CHECK_ARG(npos > 0, "empty sequence: mean over zero positions");
+  D3PM_CHECK_ARG(pred && x0 && x_t && t && per_seq, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  // sample_prior builds a float32 1/K and takes its float32 log (losses.py:11-12,60)
+  const double log_prior = (double)logf(1.0f / (float)tb->K);
+  return dispatch_layout((int)ld, false, [&](auto lay) {
+    using L = decltype(lay);
+    ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, L::G);
+    const size_t need = (size_t)B * a.chunks * sizeof(double);
+    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    double* part = (double*)workspace;
+    const dim3 grid(B * a.chunks), block(PBLOCK);
+    if (dpred)
+      hipLaunchKernelGGL((k_lvb_loss<L, true>), grid, block, 0, s, a, pred, ld, q, tmax, msa, grad_scale, log_prior,
+                         part, dpred);
+    else
+      hipLaunchKernelGGL((k_lvb_loss<L, false>), grid, block, 0, s, a, pred, ld, q, tmax, msa, grad_scale, log_prior,
+                         part, dpred);
+    D3PM_LAUNCH_CHECK("k_lvb_loss");
+    hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);
+    D3PM_LAUNCH_CHECK("k_lvb_finalize");
+    return D3PM_OK;
+  });
+}
+
+extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,
+                                     const int64_t* t, int B, long npos, const double* expo, uint64_t seed,
+                                     uint64_t offset, int64_t* out, void* stream) {
+  if (int rc = check_prot(tb, B, npos)) return rc;
+  D3PM_CHECK_ARG(ld >= tb->K, "row stride %ld smaller than K=%d", ld, tb->K);
+  if (B == 0 || npos == 0) return D3PM_OK;
+  D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
+  return dispatch_layout(tb->K, false, [&](auto lay) {
+    using L = decltype(lay);
+    ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
+    hipLaunchKernelGGL(k_lvb_reverse<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred, ld, expo,
+                       seed, offset, out);
+    D3PM_LAUNCH_CHECK("k_lvb_reverse");
+    return D3PM_OK;
+  });
+}

@@ -1,0 +1,399 @@
+"""``DiscreteDiffusion`` with the reference's constructor and method signatures
+(d3pm/diffusion_discrete.py:29-629), executed by the HIP kernels of
+libd3pm_hip.so.
+
+Differences a caller can see, all additive:
+  * tensors must live on a HIP device; there is no CPU execution path;
+  * ``q_sample`` / ``p_sample`` accept ``noise_kind`` ('uniform' as in the
+    reference, or 'gumbel' for pre-transformed noise) and ``noise=None`` for
+    on-device Philox noise; ``training_losses`` accepts optional ``t`` and
+    ``noise`` so a run can be replayed;
+  * data of any shape [B, ...] is accepted (the reference hard-codes 4-D data).
+The loss methods are differentiable with respect to the denoiser output only;
+the gradient comes out of the same kernel launch as the loss.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from .._lib import lib, check, ptr, stream_ptr, tok_bytes
+from ..tables import ImageTables
+from . import utils
+
+
+def generate_betas(start: float, stop: float, num_steps: int, type: str):
+    """Noise schedules (d3pm/diffusion_discrete.py:12-26); float64 tensor [T]."""
+    if type == "linear":
+        b = np.linspace(start, stop, num_steps)
+    elif type == "cosine":
+        grid = np.arange(num_steps + 1, dtype=np.float64) / num_steps
+        abar = np.cos((grid + 0.008) / 1.008 * np.pi / 2)
+        b = np.minimum(1 - abar[1:] / abar[:-1], 0.999)
+    elif type == "jsd":
+        b = 1.0 / np.linspace(num_steps, 1.0, num_steps)
+    else:
+        raise NotImplementedError(type)
+    return torch.tensor(b)
+
+
+def _as_tokens(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype not in (torch.int32, torch.int64):
+        x = x.to(torch.int64)
+    return x.contiguous()
+
+
+def _philox_ticket(device) -> tuple:
+    """(seed, offset) from torch's generator for `device`; advances it, so
+    torch.manual_seed() makes runs repeatable."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, off
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss[B] = (vb | ce | vb + lambda*ce) of one batch; d loss / d logits is
+    produced by the same kernel with `baked` as upstream gradient and rescaled
+    in place in backward only if the real upstream differs."""
+
+    @staticmethod
+    def forward(ctx, logits, x0, x_t, t, tables, loss_type, lam, baked):
+        B = x0.shape[0]
+        K = tables.K
+        npos = x0.numel() // max(B, 1)
+        lg = logits.contiguous()
+        if lg.dtype != torch.float32:
+            lg = lg.float()
+        want_grad = ctx.needs_input_grad[0]
+        loss = torch.empty(B, dtype=torch.float32, device=lg.device)
+        dl = torch.empty_like(lg) if want_grad else None
+        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, K)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=lg.device)
+        check(lib.d3pm_hybrid_loss(tables.desc(), ptr(lg), K, ptr(x0), tok_bytes(x0), ptr(x_t), tok_bytes(x_t),
+                                   ptr(t), tok_bytes(t), B, npos, loss_type, float(lam), float(baked), None,
+                                   None, None, ptr(loss), ptr(dl), ptr(ws), ws_bytes, stream_ptr()))
+        ctx.dl, ctx.baked, ctx.shape, ctx.dtype = dl, float(baked), logits.shape, logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl = ctx.dl
+        if dl is None:
+            return (None,) * 8
+        if getattr(ctx, "spent", False):
+            raise RuntimeError("the fused D3PM loss keeps one gradient buffer: backward twice is not supported")
+        ctx.spent = True
+        g = g.contiguous().float()
+        B = g.shape[0]
+        check(lib.d3pm_scale_rows(ptr(dl), ptr(g), ctx.baked, B, dl.numel() // max(B, 1), stream_ptr()))
+        out = dl.view(ctx.shape)
+        if out.dtype != ctx.dtype:
+            out = out.to(ctx.dtype)
+        return out, None, None, None, None, None, None, None
+
+
+class DiscreteDiffusion:
+    """Discrete state space diffusion process (d3pm/diffusion_discrete.py:29)."""
+
+    def __init__(self, betas, transition_mat_type, num_bits, transition_bands, model_prediction, model_output,
+                 loss_type, hybrid_coeff, device, torch_dtype=torch.float32):
+        self.device = torch.device(device)
+        self.model_prediction = model_prediction    # 'x_start' | 'xprev'
+        self.model_output = model_output            # 'logits' | 'logistic_pars'
+        self.loss_type = loss_type                  # 'kl' | 'hybrid' | 'cross_entropy_x_start'
+        self.hybrid_coeff = hybrid_coeff
+        self.torch_dtype = torch_dtype
+        self.num_bits = num_bits
+        self.num_pixel_vals = 2 ** num_bits
+        self.transition_bands = transition_bands
+        self.transition_mat_type = transition_mat_type
+        self.eps = 1.0e-6
+
+        if not isinstance(betas, torch.Tensor):
+            raise ValueError("expected betas to be a torch Tensor")
+        if not ((betas > 0).all() and (betas <= 1).all()):
+            raise ValueError("betas must be in (0, 1]")
+        if transition_mat_type not in _lib.KIND:
+            raise ValueError(f"transition_mat_type must be 'gaussian', 'uniform', 'absorbing', "
+                             f"but is {transition_mat_type}")
+        if self.device.type != "cuda":
+            raise RuntimeError("DiscreteDiffusion runs on HIP kernels only: pass device='cuda' "
+                               "(there is no CPU path in this package)")
+        if torch_dtype != torch.float32:
+            raise NotImplementedError("the kernels compute in float32, like the reference's default torch_dtype")
+        self.betas = betas.detach().to(dtype=torch.float64)
+        self.num_timesteps = T = self.betas.shape[0]
+        K = self.num_pixel_vals
+        with torch.cuda.device(self.device):
+            b_dev = self.betas.to(self.device).contiguous()
+            onestep = torch.empty((T, K, K), dtype=torch.float64, device=self.device)
+            q_mats = torch.empty((T, K, K), dtype=torch.float64, device=self.device)
+            bands = -1 if transition_bands is None else int(transition_bands)
+            check(lib.d3pm_build_tables_f64(_lib.KIND[transition_mat_type], K, T, bands, ptr(b_dev), ptr(onestep),
+                                            ptr(q_mats), stream_ptr()))
+        # q(x_t | x_start) and the transposed one-step matrices, as in :90,:97
+        self.q_mats = q_mats
+        self.transpose_q_onestep_mats = onestep.permute(0, 2, 1)
+        self._tables: Optional[ImageTables] = None
+        self._tables_key = None
+        self.force_dense = False
+
+    # ------------------------------------------------------------------ tables
+    def tables(self) -> ImageTables:
+        """Digest / float32 copies of the current ``q_mats`` and
+        ``transpose_q_onestep_mats`` (rebuilt if a caller replaced them)."""
+        a, b = self.q_mats, self.transpose_q_onestep_mats
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, tuple(b.stride()), self.force_dense)
+        if self._tables is None or key != self._tables_key:
+            with torch.cuda.device(self.device):
+                self._tables = ImageTables(a.to(self.device), b.to(self.device), eps=self.eps,
+                                           transposed_onestep=True, force_dense=self.force_dense)
+            self._tables_key = key
+        return self._tables
+
+    def _dims(self, x):
+        B = x.shape[0]
+        return B, (x.numel() // B if B else 0)
+
+    # ------------------------------------------------------------------ gathers (API compatibility)
+    def _at(self, a, t, x):
+        """a[t_b, x] as float32 (:205-226).  The kernels fuse this gather; the
+        method is kept for callers that use it on their own tables."""
+        a32 = a.to(dtype=self.torch_dtype)
+        tb = t.long().view(-1, *([1] * (x.dim() - 1)))
+        return a32[tb, x.long()]
+
+    def _at_onehot(self, a, t, x):
+        """x @ a[t_b] (:229-247), kept for API compatibility."""
+        a32 = a.to(dtype=self.torch_dtype)[t.long()]
+        return torch.matmul(x, a32.view(a32.shape[0], *([1] * (x.dim() - 2)), *a32.shape[1:]))
+
+    # ------------------------------------------------------------------ forward process
+    def q_probs(self, x_start, t):
+        """q(x_t | x_start) as float32 [..., K] (:250-263)."""
+        x = _as_tokens(x_start)
+        tb = self.tables()
+        B, npos = self._dims(x)
+        out = torch.empty(x.shape + (tb.K,), dtype=torch.float32, device=x.device)
+        t = _as_tokens(t)
+        with torch.cuda.device(x.device):
+            check(lib.d3pm_q_probs(tb.desc(), ptr(x), tok_bytes(x), ptr(t), tok_bytes(t), B, npos, ptr(out),
+                                   stream_ptr()))
+        return out
+
+    def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform"):
+        """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64."""
+        x = _as_tokens(x_start)
+        _lib.require_device(x)
+        tb = self.tables()
+        B, npos = self._dims(x)
+        t = _as_tokens(t)
+        seed = off = 0
+        if noise is None:
+            kind = _lib.NOISE_PHILOX
+            seed, off = _philox_ticket(x.device)
+        else:
+            assert noise.shape == x.shape + (tb.K,), noise.shape
+            kind = _lib.NOISE[noise_kind]
+            noise = noise.contiguous().float()
+        out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.d3pm_q_sample(tb.desc(), ptr(x), tok_bytes(x), ptr(t), tok_bytes(t), B, npos, ptr(noise), kind,
+                                    seed, off, ptr(out), stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ posterior
+    def _get_logits_from_logistic_pars(self, loc, log_scale):
+        """Logits of a discretised logistic (:288-309); elementwise tensor ops."""
+        loc, log_scale = loc.unsqueeze(-1), log_scale.unsqueeze(-1)
+        inv_scale = torch.exp(-(log_scale - 2.0))
+        K = self.num_pixel_vals
+        width = 2.0 / (K - 1.0)
+        centers = torch.linspace(-1.0, 1.0, K, device=loc.device).view(*([1] * (loc.dim() - 1)), K) - loc
+        lo = F.logsigmoid(inv_scale * (centers - 0.5 * width))
+        hi = F.logsigmoid(inv_scale * (centers + 0.5 * width))
+        return utils.log_min_exp(hi, lo, self.eps)
+
+    def q_posterior_logits(self, x_start, x_t, t, x_start_logits):
+        """Logits of q(x_{t-1} | x_t, x_start) (:312-336)."""
+        K = self.num_pixel_vals
+        if x_start_logits:
+            assert x_start.shape == x_t.shape + (K,), (x_start.shape, x_t.shape)
+            xs = x_start.contiguous().float()
+        else:
+            assert x_start.shape == x_t.shape, (x_start.shape, x_t.shape)
+            xs = _as_tokens(x_start)
+        xt, t = _as_tokens(x_t), _as_tokens(t)
+        _lib.require_device(xs, xt)
+        tb = self.tables()
+        B, npos = self._dims(xt)
+        out = torch.empty(xt.shape + (K,), dtype=torch.float32, device=xt.device)
+        with torch.cuda.device(xt.device):
+            check(lib.d3pm_q_posterior_logits(tb.desc(), ptr(xs), int(bool(x_start_logits)), K,
+                                              8 if x_start_logits else tok_bytes(xs), ptr(xt), tok_bytes(xt),
+                                              ptr(t), tok_bytes(t), B, npos, ptr(out), stream_ptr()))
+        return out
+
+    def _denoiser_logits(self, model_fn, x, t):
+        out = model_fn(x, t)
+        if self.model_output == "logits":
+            return out
+        if self.model_output == "logistic_pars":
+            loc, log_scale = out
+            return self._get_logits_from_logistic_pars(loc, log_scale)
+        raise NotImplementedError(self.model_output)
+
+    def p_logits(self, model_fn, *, x, t):
+        """Logits of p(x_{t-1} | x_t) and the predicted x_start logits (:339-381)."""
+        assert t.shape == (x.shape[0],)
+        pred = self._denoiser_logits(model_fn, x, t)
+        if self.model_prediction != "x_start":
+            raise NotImplementedError(self.model_prediction)
+        with torch.no_grad():
+            ml = self.q_posterior_logits(pred.detach(), x, t, x_start_logits=True)
+        assert ml.shape == pred.shape == x.shape + (self.num_pixel_vals,)
+        return ml, pred
+
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def p_sample(self, model_fn, *, x, t, noise=None, noise_kind: str = "uniform"):
+        """One reverse step (:384-403): (sample int64, softmax(pred_x_start))."""
+        assert t.shape == (x.shape[0],)
+        pred = self._denoiser_logits(model_fn, x, t)
+        if self.model_prediction != "x_start":
+            raise NotImplementedError(self.model_prediction)
+        return self._p_sample_from_logits(pred, x, t, noise, noise_kind, want_probs=True)
+
+    def _p_sample_from_logits(self, pred, x, t, noise, noise_kind, want_probs):
+        K = self.num_pixel_vals
+        lg = pred.contiguous().float()
+        xt, t = _as_tokens(x), _as_tokens(t)
+        _lib.require_device(lg, xt)
+        assert lg.shape == xt.shape + (K,), lg.shape
+        tb = self.tables()
+        B, npos = self._dims(xt)
+        seed = off = 0
+        if noise is None:
+            kind = _lib.NOISE_PHILOX
+            seed, off = _philox_ticket(xt.device)
+        else:
+            assert noise.shape == lg.shape, noise.shape
+            kind = _lib.NOISE[noise_kind]
+            noise = noise.contiguous().float()
+        sample = torch.empty(xt.shape, dtype=torch.int64, device=xt.device)
+        probs = torch.empty_like(lg) if want_probs else None
+        with torch.cuda.device(xt.device):
+            check(lib.d3pm_p_sample(tb.desc(), ptr(lg), K, ptr(xt), tok_bytes(xt), ptr(t), tok_bytes(t), B, npos,
+                                    ptr(noise), kind, seed, off, ptr(sample), ptr(probs), stream_ptr()))
+        return sample, probs
+
+    @torch.no_grad()
+    def p_sample_loop(self, model_fn, *, shape, num_timesteps=None, return_x_init=False, return_im_steps=False,
+                      save_interval=None):
+        """Ancestral sampling (:405-458); noise is drawn on device per step."""
+        shape = tuple(shape)
+        K = self.num_pixel_vals
+        if self.transition_mat_type in ("gaussian", "uniform"):
+            x_init = torch.randint(low=0, high=K, size=shape, device=self.device)
+        elif self.transition_mat_type == "absorbing":
+            x_init = torch.full(size=shape, fill_value=K // 2, dtype=torch.int32, device=self.device)
+        else:
+            raise ValueError(f"transition_mat_type must be 'gaussian', 'uniform', 'absorbing', "
+                             f"but is {self.transition_mat_type}")
+        if num_timesteps is None:
+            num_timesteps = self.num_timesteps
+        x = x_init
+        keep = [x.detach().cpu()] if (return_im_steps and save_interval is not None) else None
+        for i in range(num_timesteps):
+            t = torch.full([shape[0]], self.num_timesteps - 1 - i, device=self.device)
+            pred = self._denoiser_logits(model_fn, x, t)
+            x, _ = self._p_sample_from_logits(pred, x, t, None, "uniform", want_probs=False)
+            if keep is not None and (i + 1) % save_interval == 0:
+                keep.append(x.detach().cpu())
+        if keep is not None:
+            return keep
+        assert x.shape == shape
+        return (x_init, x) if return_x_init else x
+
+    # ------------------------------------------------------------------ losses
+    def _fused(self, pred, x_start, x_t, t, loss_type: str, baked: Optional[float] = None):
+        x0, xt, t = _as_tokens(x_start), _as_tokens(x_t), _as_tokens(t)
+        _lib.require_device(pred, x0, xt)
+        assert pred.shape == x0.shape + (self.num_pixel_vals,), pred.shape
+        B = x0.shape[0]
+        if baked is None:
+            baked = float(np.float32(1.0) / np.float32(max(B, 1)))    # upstream of `.mean()`
+        with torch.cuda.device(x0.device):
+            return _FusedLoss.apply(pred, x0, xt, t, self.tables(), _lib.LOSS[loss_type], self.hybrid_coeff or 0.0,
+                                    baked)
+
+    def vb_terms_bpd(self, model_fn, *, x_start, x_t, t):
+        """Variational-bound terms in bits/dim (:462-489): (vb[B], pred logits)."""
+        pred = self._denoiser_logits(model_fn, x_t, t)
+        if self.model_prediction != "x_start":
+            raise NotImplementedError(self.model_prediction)
+        vb = self._fused(pred, x_start, x_t, t, "kl")
+        assert vb.shape == t.shape == (x_start.shape[0],)
+        return vb, pred
+
+    def prior_bpd(self, x_start):
+        """KL(q(x_{T-1}|x_start) || stationary) in bits/dim (:492-524)."""
+        if self.transition_mat_type not in ("gaussian", "uniform", "absorbing"):
+            raise ValueError(f"transition_mat_type must be 'gaussian', 'uniform', 'absorbing', "
+                             f"but is {self.transition_mat_type}")
+        x = _as_tokens(x_start)
+        _lib.require_device(x)
+        tb = self.tables()
+        B, npos = self._dims(x)
+        out = torch.empty(B, dtype=torch.float32, device=x.device)
+        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.d3pm_prior_bpd(tb.desc(), ptr(x), tok_bytes(x), B, npos,
+                                     int(self.transition_mat_type == "absorbing"), ptr(out), ptr(ws), ws_bytes,
+                                     stream_ptr()))
+        return out
+
+    def cross_entropy_start(self, x_start, pred_x_start_logits):
+        """Cross entropy of x_start under the predicted logits, bits/dim (:527-542)."""
+        x0 = _as_tokens(x_start)
+        t0 = torch.zeros(x0.shape[0], dtype=torch.int32, device=x0.device)
+        ce = self._fused(pred_x_start_logits, x0, x0, t0, "cross_entropy_x_start")
+        assert ce.shape == (x_start.shape[0],)
+        return ce
+
+    def training_losses(self, model_fn, *, x_start, t=None, noise=None, noise_kind: str = "uniform"):
+        """Per-example training loss (:545-582).  `t` and `noise` default to
+        on-device draws (uniform t in [0, T), Philox noise)."""
+        if self.loss_type not in _lib.LOSS:
+            raise NotImplementedError(self.loss_type)
+        B = x_start.shape[0]
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (B,), dtype=torch.int32, device=self.device)
+        x_t = self.q_sample(x_start=x_start, t=t, noise=noise, noise_kind=noise_kind)
+        pred = self._denoiser_logits(model_fn, x_t, t)
+        if self.model_prediction != "x_start":
+            raise NotImplementedError(self.model_prediction)
+        losses = self._fused(pred, x_start, x_t, t, self.loss_type)
+        assert losses.shape == t.shape
+        return losses
+
+    @torch.no_grad()
+    def calc_bpd_loop(self, model_fn, *, x_start):
+        """Variational bound over all timesteps (:584-629)."""
+        B = x_start.shape[0]
+        vb_tb = torch.empty((self.num_timesteps, B), dtype=torch.float32, device=self.device)
+        for step in range(self.num_timesteps):
+            t = torch.full((B,), step, dtype=torch.int32, device=self.device)
+            x_t = self.q_sample(x_start=x_start, t=t)
+            vb_tb[step], _ = self.vb_terms_bpd(model_fn=model_fn, x_start=x_start, x_t=x_t, t=t)
+        prior = self.prior_bpd(x_start=x_start)
+        total = vb_tb.sum(dim=0) + prior
+        assert prior.shape == total.shape == (B,)
+        return {"total": total, "vbterms": vb_tb.T, "prior": prior}

@@ -1,0 +1,132 @@
+"""LVB loss of the protein-style D3PM with the constructor and ``forward``
+signatures of ``protein_generation/losses.py`` (:24-155), computed per batch in
+one kernel launch (no Python loop over sequences, no [L,K,K] temporaries, no
+host synchronisation on the timesteps).
+
+``forward`` takes the reference's eight positional tensors.  The one-hot
+arguments are redundant for the kernels: pass integer tokens through the
+optional ``src=`` keyword (the corrupted sequence the collater also returns) to
+skip the argmax that otherwise recovers them from ``src_onehot``."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.nn import KLDivLoss
+
+from .. import _lib
+from .._lib import lib, check, ptr, stream_ptr
+from ..tables import protein_tables
+from .constants import MSA_AAS
+from .utils import Tokenizer
+
+
+def sample_prior(a, b, len=len(MSA_AAS)):
+    """Uniform prior [a,b] over `len` values (losses.py:6-13)."""
+    return torch.ones(a, b) / len
+
+
+def sample_priorMSA(a, b, c, len=len(MSA_AAS)):
+    """Uniform prior [a,b,c] (losses.py:15-22)."""
+    return torch.ones(a, b, c) / len
+
+
+def KL_test(q, tokenizer):
+    """KL(q || uniform), batchmean (losses.py:159-162)."""
+    prior = sample_priorMSA(q.shape[0], q.shape[1], q.shape[2], len=tokenizer.K).to(q.device)
+    return KLDivLoss(reduction="batchmean", log_target=False)(prior.log(), q)
+
+
+class _LVB(torch.autograd.Function):
+    """per_seq[B] (float64) and, in the same launch, d(baked * sum per_seq)/d pred."""
+
+    @staticmethod
+    def forward(ctx, pred, x0, x_t, t, q, tables, tmax, msa, baked):
+        B = x0.shape[0]
+        npos = x0.numel() // max(B, 1)
+        pr = pred.contiguous()
+        if pr.dtype != torch.float32:
+            pr = pr.float()
+        ld = pr.shape[-1]
+        want_grad = ctx.needs_input_grad[0]
+        per = torch.empty(B, dtype=torch.float64, device=pr.device)
+        dp = torch.empty_like(pr) if want_grad else None
+        ws_bytes = lib.d3pm_lvb_loss_workspace(B, npos, tables.K)
+        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=pr.device)
+        check(lib.d3pm_lvb_loss(tables.desc(), ptr(pr), ld, ptr(x0), ptr(x_t), ptr(t), ptr(q), B, npos, int(tmax),
+                                int(msa), float(baked), ptr(per), ptr(dp), ptr(ws), ws_bytes, stream_ptr()))
+        ctx.dp, ctx.baked, ctx.shape, ctx.dtype = dp, float(np.float32(baked)), pred.shape, pred.dtype
+        return per
+
+    @staticmethod
+    def backward(ctx, g):
+        dp = ctx.dp
+        if dp is None:
+            return (None,) * 9
+        if getattr(ctx, "spent", False):
+            raise RuntimeError("the fused LVB loss keeps one gradient buffer: backward twice is not supported")
+        ctx.spent = True
+        g = g.contiguous().float()
+        B = g.shape[0]
+        check(lib.d3pm_scale_rows(ptr(dp), ptr(g), ctx.baked, B, dp.numel() // max(B, 1), stream_ptr()))
+        out = dp.view(ctx.shape)
+        if out.dtype != ctx.dtype:
+            out = out.to(ctx.dtype)
+        return out, None, None, None, None, None, None, None, None
+
+
+def _lvb_forward(self, src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, msa, src=None):
+    _lib.require_device(predictions)
+    dev = predictions.device
+    K = self.K
+    x0 = tgt.to(device=dev, dtype=torch.int64).contiguous()
+    if src is None:
+        src = src_onehot.to(dev)[..., :K].argmax(dim=-1)
+    x_t = src.to(device=dev, dtype=torch.int64).contiguous()
+    t = timestep.to(device=dev, dtype=torch.int64).contiguous()
+    assert x_t.shape == x0.shape and t.shape == (x0.shape[0],)
+    assert predictions.shape[:-1] == x0.shape and predictions.shape[-1] >= K
+    qd = None
+    if q is not None:
+        qd = q.to(device=dev, dtype=torch.float64).contiguous()
+        assert qd.shape == x0.shape + (K,), qd.shape
+    tables = protein_tables(Q, Q_bar, device=dev)
+    B = x0.shape[0]
+    baked = 1.0 if self.evaluation else float(np.float32(1.0) / np.float32(max(B, 1)))
+    depth = int(x0.shape[1]) if msa else 0            # [B, D, L]: MSA depth
+    with torch.cuda.device(dev):
+        per = _LVB.apply(predictions, x0, x_t, t, qd, tables, self.tmax, depth, baked)
+    if self.evaluation:
+        return per                                   # losses.py:89-90
+    return per.sum() / B                             # losses.py:92
+
+
+class D3PMLVBLoss(KLDivLoss):
+    """losses.py:24-93.  Inputs (names as in the reference's code, which swaps
+    the roles its docstring gives): src_onehot [B,L,K] one-hot of the corrupted
+    x_t, q [B,L,K] forward probabilities, predicitons [B,L,n_tokens] logits,
+    tgt [B,L] clean tokens x_0, tgt_onehot, timestep [B], Q / Q_bar [T,K,K]."""
+
+    def __init__(self, tmax=500, reduction="batchmean", log_target=False, tokenizer=None, evaluation=None):
+        super().__init__(reduction=reduction, log_target=log_target)
+        self.tmax = tmax
+        self.tokenizer = tokenizer if tokenizer is not None else Tokenizer()
+        self.K = self.tokenizer.K
+        self.evaluation = evaluation
+
+    def forward(self, src_onehot, q, predicitons, tgt, tgt_onehot, timestep, Q, Q_bar, src=None):
+        return _lvb_forward(self, src_onehot, q, predicitons, tgt, tgt_onehot, timestep, Q, Q_bar, msa=False, src=src)
+
+
+class D3PMLVBLossMSA(KLDivLoss):
+    """losses.py:96-155: same over [B,D,L,...] inputs; the posterior is divided
+    by Qbar_{t-1}[x0, x_t] as in the reference (:148)."""
+
+    def __init__(self, tmax=500, reduction="batchmean", log_target=False, tokenizer=None):
+        super().__init__(reduction=reduction, log_target=log_target)
+        self.tmax = tmax
+        self.tokenizer = tokenizer if tokenizer is not None else Tokenizer()
+        self.K = self.tokenizer.K
+        self.evaluation = None
+
+    def forward(self, src_one_hot, q, predictions, tgt, tgt_one_hot, timestep, Q, Q_bar, src=None):
+        return _lvb_forward(self, src_one_hot, q, predictions, tgt, tgt_one_hot, timestep, Q, Q_bar, msa=True, src=src)

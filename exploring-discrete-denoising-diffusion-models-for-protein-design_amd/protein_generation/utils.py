@@ -1,0 +1,131 @@
+"""Schedules, tables, tokenizer and forward corruption of the protein-style
+process, with the names and return conventions of
+``protein_generation/utils.py`` (:7-102).  Tables are built and multiplied on
+the device; forward corruption is one batched kernel launch instead of a
+per-sequence ``torch.multinomial``."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import lib, check, ptr, stream_ptr
+from ..tables import ProteinTables
+from .constants import PROTEIN_ALPHABET, MSA_AAS, GAP
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the protein-style kernels need a HIP device; there is no CPU path in this package")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def cumprod_matrix(a):
+    """Running products a[0], a[0]a[1], ... (utils.py:7-18).  `a` is a list of
+    [K,K] matrices or a [T,K,K] tensor; returns a list of T device tensors."""
+    stack = a if torch.is_tensor(a) else torch.stack(list(a))
+    dev = stack.device if stack.is_cuda else _default_device()
+    stack = stack.to(device=dev, dtype=torch.float64)
+    T, K = stack.shape[0], stack.shape[1]
+    out = torch.empty((T, K, K), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.d3pm_cumprod_f64(K, T, ptr(stack), stack.stride(0), stack.stride(1), stack.stride(2), ptr(out),
+                                   stream_ptr()))
+    return list(out.unbind(0))
+
+
+def _beta_schedule(num_steps, start=1e-5, end=0.999, schedule="linear"):
+    """float32 beta schedules (utils.py:28-41); host-side, T scalars."""
+    if schedule == "linear":
+        return torch.linspace(start, end, num_steps)
+    if schedule == "cosine":
+        return torch.cos(torch.linspace(np.pi / 2, 0, num_steps)) * (end - start) + start
+    if schedule == "sohl-dickstein":
+        return 1 / (num_steps - torch.linspace(0, num_steps - 1, num_steps) + 1)
+    raise NotImplementedError(schedule)
+
+
+def sample_transition_matrix(x_0, Q_bar, noise=None):
+    """x_t ~ Categorical(x_0 @ Q_bar) for one sequence (utils.py:44-52):
+    returns (sample [L] int64, probabilities [L,K] float64).  ``x_0`` is the
+    one-hot [L,K] float64 the reference passes, ``Q_bar`` one [K,K] matrix.
+    ``noise`` optionally supplies the Exp(1) draw [L,K] of torch.multinomial."""
+    dev = x_0.device if x_0.is_cuda else _default_device()
+    x0 = x_0.to(dev).argmax(dim=-1).unsqueeze(0)                       # [1, L]
+    Qb = Q_bar.to(device=dev, dtype=torch.float64).unsqueeze(0)        # T = 1
+    tb = ProteinTables(Qb, Qb)
+    s, p = corrupt_batch(tb, x0, torch.zeros(1, dtype=torch.int64, device=dev),
+                         None if noise is None else noise.unsqueeze(0), want_probs=True)
+    return s[0], p[0]
+
+
+def corrupt_batch(tables: ProteinTables, x0, t, noise=None, want_probs=False):
+    """Batched forward corruption: x0 [B,L] int64, t [B] int64 ->
+    (x_t [B,L] int64, q(x_t|x0) [B,L,K] float64 or None)."""
+    from ..d3pm.diffusion_discrete import _philox_ticket
+    x0 = x0.to(torch.int64).contiguous()
+    t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+    _lib.require_device(x0)
+    B = x0.shape[0]
+    npos = x0.numel() // max(B, 1)
+    seed = off = 0
+    if noise is None:
+        seed, off = _philox_ticket(x0.device)
+    else:
+        noise = noise.to(device=x0.device, dtype=torch.float64).contiguous()
+        assert noise.shape == x0.shape + (tables.K,), noise.shape
+    x_t = torch.empty_like(x0)
+    probs = torch.empty(x0.shape + (tables.K,), dtype=torch.float64, device=x0.device) if want_probs else None
+    with torch.cuda.device(x0.device):
+        check(lib.d3pm_corrupt(tables.desc(), ptr(x0), ptr(t), B, npos, ptr(noise), seed, off, ptr(x_t), ptr(probs),
+                               stream_ptr()))
+    return x_t, probs
+
+
+class Tokenizer(object):
+    """Character <-> index maps and the uniform transition schedule
+    (utils.py:55-102)."""
+
+    def __init__(self, protein_alphabet=PROTEIN_ALPHABET, all_aas=MSA_AAS, gap=GAP):
+        self.alphabet = list("".join(protein_alphabet))
+        self.all_aas = list("".join(all_aas))
+        self.gap = gap
+        self.a_to_i = {u: i for i, u in enumerate(self.alphabet)}
+        self.i_to_a = np.array(self.alphabet)
+        self.K = len(self.all_aas)
+
+    def q_uniform_schedule(self, num_steps=500, schedule="sohl-dickstein", device=None):
+        """(Q_prod, Q_t), both [T,K,K] float64 on the device (utils.py:65-83).
+
+        The two float32 scalars per step of the reference (the off-diagonal
+        ones/K*beta_t and 1 - its column sum) are evaluated with the same
+        tensor expression on the host so that their float32 rounding is the
+        reference's; the matrices and their running products are built on the
+        device."""
+        dev = torch.device(device) if device is not None else _default_device()
+        betas = _beta_schedule(num_steps=num_steps, schedule=schedule)
+        K, T = self.K, len(betas)
+        col = torch.ones((K, K)) / K * betas.view(T, 1, 1)           # [T,K,K] float32
+        off = col[:, 0, 0].contiguous()
+        norm = torch.stack([1 - col[i].sum(axis=0)[0] for i in range(T)])
+        Q_t = torch.empty((T, K, K), dtype=torch.float64, device=dev)
+        Q_prod = torch.empty_like(Q_t)
+        off_d, norm_d = off.to(dev), norm.contiguous().to(dev)     # named: must outlive the launch
+        with torch.cuda.device(dev):
+            check(lib.d3pm_protein_uniform_tables_f64(K, T, ptr(off_d), ptr(norm_d), ptr(Q_t), ptr(Q_prod),
+                                                      stream_ptr()))
+        return Q_prod, Q_t
+
+    def tokenize(self, seq):
+        return np.array([self.a_to_i[a] for a in seq])
+
+    def untokenize(self, x):
+        if torch.is_tensor(x):
+            x = x.detach().cpu().tolist()
+        return "".join(self.i_to_a[int(i)] for i in x)
+
+    def one_hot(self, tokenized):
+        return torch.nn.functional.one_hot(tokenized, num_classes=self.K).to(torch.double)
+
+    def undo_one_hot(self, x_onehot):
+        return [np.where(r == 1)[0] for r in x_onehot]

@@ -1,0 +1,128 @@
+"""Device-resident transition tables and the digests the kernels read.
+
+``ImageTables`` serves the image-style process (float32 semantics of
+``DiscreteDiffusion._at`` / ``_at_onehot``); ``ProteinTables`` serves the
+protein-style kernels (float64).  Both are built once per (Q_t, Qbar) pair and
+cached: the reference re-casts (image style) or re-uploads (protein style) the
+whole tables on every call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+
+
+def _strides3(t: torch.Tensor) -> Tuple[int, int, int]:
+    assert t.dim() == 3
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+class ImageTables:
+    """float32 view of (one-step Q_t, cumulative Qbar_t) for d3pm-style kernels.
+
+    ``q_onestep`` is indexed [t, from, to]; pass ``transposed_onestep=True`` if
+    the tensor is the reference's ``transpose_q_onestep_mats`` ([t, to, from]).
+    Column-structured tables (uniform, absorbing) get the O(K) digest path;
+    anything else (Gaussian, banded) the dense path with float32 copies.
+    """
+
+    def __init__(self, q_mats: torch.Tensor, q_onestep: torch.Tensor, eps: float = 1e-6,
+                 transposed_onestep: bool = False, force_dense: bool = False):
+        _lib.require_device(q_mats, q_onestep)
+        if q_mats.dtype != torch.float64 or q_onestep.dtype != torch.float64:
+            q_mats, q_onestep = q_mats.double(), q_onestep.double()
+        assert q_mats.dim() == 3 and q_mats.shape == q_onestep.shape and q_mats.shape[1] == q_mats.shape[2]
+        self.T, self.K = int(q_mats.shape[0]), int(q_mats.shape[1])
+        self.eps = float(eps)
+        self.device = q_mats.device
+        if transposed_onestep:
+            q_onestep = q_onestep.permute(0, 2, 1)       # back to [t, from, to], no copy
+        self._keep = (q_mats, q_onestep)
+        T, K = self.T, self.K
+        with torch.cuda.device(self.device):
+            s = stream_ptr()
+            self.qbar_digest = torch.empty((T, 4, K), dtype=torch.float32, device=self.device)
+            self.qone_digest = torch.empty((T, 4, K), dtype=torch.float32, device=self.device)
+            viol = torch.zeros(2, dtype=torch.int32, device=self.device)
+            check(lib.d3pm_digest_f32(ptr(q_mats), *_strides3(q_mats), T, K, self.eps, ptr(self.qbar_digest),
+                                      viol.data_ptr(), s))
+            check(lib.d3pm_digest_f32(ptr(q_onestep), *_strides3(q_onestep), T, K, self.eps,
+                                      ptr(self.qone_digest), viol.data_ptr() + 4, s))
+            self.violations = tuple(int(v) for v in viol.tolist())     # one sync, at set-up
+            self.structured = (self.violations == (0, 0)) and not force_dense
+            self.qbar = self.qoneT = self.qbarT = None
+            if not self.structured:
+                self.qbar = torch.empty((T, K, K), dtype=torch.float32, device=self.device)
+                self.qoneT = torch.empty_like(self.qbar)
+                self.qbarT = torch.empty_like(self.qbar)
+                check(lib.d3pm_table_to_f32(ptr(q_mats), *_strides3(q_mats), T, K, ptr(self.qbar), s))
+                qT = q_mats.permute(0, 2, 1)
+                check(lib.d3pm_table_to_f32(ptr(qT), *_strides3(qT), T, K, ptr(self.qbarT), s))
+                oT = q_onestep.permute(0, 2, 1)
+                check(lib.d3pm_table_to_f32(ptr(oT), *_strides3(oT), T, K, ptr(self.qoneT), s))
+        self._desc = _lib.TablesF32(K, T, int(self.structured), self.eps, ptr(self.qbar_digest),
+                                    ptr(self.qone_digest), ptr(self.qbar), ptr(self.qoneT), ptr(self.qbarT))
+
+    def desc(self):
+        return C.byref(self._desc)
+
+
+class ProteinTables:
+    """float64 column-structured digests of (Q_t, Qbar_t) for the protein-style
+    kernels.  Raises NotImplementedError for tables without that structure."""
+
+    RTOL = 1e-9
+
+    def __init__(self, Q: torch.Tensor, Q_bar: torch.Tensor):
+        _lib.require_device(Q, Q_bar)
+        assert Q.dim() == 3 and Q.shape == Q_bar.shape and Q.shape[1] == Q.shape[2]
+        if Q.dtype != torch.float64 or Q_bar.dtype != torch.float64:
+            Q, Q_bar = Q.double(), Q_bar.double()
+        self.T, self.K = int(Q.shape[0]), int(Q.shape[1])
+        self.device = Q.device
+        self._keep = (Q, Q_bar)
+        T, K = self.T, self.K
+        with torch.cuda.device(self.device):
+            s = stream_ptr()
+            self.qbar_digest = torch.empty((T, 2, K), dtype=torch.float64, device=self.device)
+            self.qone_digest = torch.empty((T, 2, K), dtype=torch.float64, device=self.device)
+            viol = torch.zeros(2, dtype=torch.int32, device=self.device)
+            check(lib.d3pm_digest_f64(ptr(Q_bar), *_strides3(Q_bar), T, K, self.RTOL, ptr(self.qbar_digest),
+                                      viol.data_ptr(), s))
+            check(lib.d3pm_digest_f64(ptr(Q), *_strides3(Q), T, K, self.RTOL, ptr(self.qone_digest),
+                                      viol.data_ptr() + 4, s))
+            self.violations = tuple(int(v) for v in viol.tolist())
+        if self.violations != (0, 0):
+            raise NotImplementedError(
+                "protein-style kernels need column-structured transition tables (uniform schedule); "
+                f"{self.violations} entries break the structure")
+        self._desc = _lib.TablesF64(K, T, ptr(self.qbar_digest), ptr(self.qone_digest))
+
+    def desc(self):
+        return C.byref(self._desc)
+
+
+_protein_cache: Dict[tuple, ProteinTables] = {}
+
+
+def protein_tables(Q: torch.Tensor, Q_bar: torch.Tensor, device=None) -> ProteinTables:
+    """Cached ProteinTables for the (Q, Q_bar) pair a caller passes on every
+    call (losses.py:48, generate.py:8).  CPU tensors are uploaded once."""
+    key = (Q.data_ptr(), Q._version, Q_bar.data_ptr(), Q_bar._version, tuple(Q.shape), str(device or Q.device))
+    hit = _protein_cache.get(key)
+    if hit is not None:
+        return hit
+    dev = torch.device(device) if device is not None else Q.device
+    if dev.type != "cuda":
+        raise RuntimeError("protein-style kernels need a HIP device; there is no CPU path in this package")
+    tb = ProteinTables(Q.to(dev), Q_bar.to(dev))
+    tb._src = (Q, Q_bar)           # keep the key's storage alive so data_ptr cannot be recycled
+    if len(_protein_cache) > 8:
+        _protein_cache.clear()
+    _protein_cache[key] = tb
+    return tb

@@ -1,0 +1,216 @@
+/*
+ * d3pm_hip.h - C ABI of libd3pm_hip.so: the D3PM categorical-diffusion core for
+ * AMD MI355X (gfx950).
+ *
+ * The reference project is pure Python/PyTorch and has no FFI of its own: the
+ * boundary this library replaces is the Python call surface of its D3PM core.
+ * Every entry point below names the reference function(s) whose arithmetic it
+ * carries out (paths relative to the reference tree).  All pointers except
+ * `d3pm_*_desc` structs, and the structs' own storage, are DEVICE pointers on
+ * the current HIP device; `stream` is a hipStream_t passed as void*.  Nothing
+ * here synchronises the host with the device, allocates or frees.
+ *
+ * Token arrays are int32 or int64 (`tok_bytes` = 4 or 8), per-sample
+ * timesteps likewise (`t_bytes`).  Logits rows may be wider than K
+ * (`ld` = row stride in elements >= K); only the first K entries take part
+ * unless stated otherwise.  "npos" is the number of positions per batch
+ * element (H*W*C for images, L for sequences, D*L for MSAs); tensors are laid
+ * out [B, npos, K] row-major.
+ *
+ * Return value: D3PM_OK or an error code; d3pm_last_error() gives the message
+ * of the calling thread's last failure.
+ */
+#ifndef D3PM_HIP_H
+#define D3PM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3PM_OK            0
+#define D3PM_EINVAL        1   /* bad argument: the facade raises ValueError/AssertionError */
+#define D3PM_EUNSUPPORTED  2   /* valid but not implemented: NotImplementedError */
+#define D3PM_EHIP          3   /* HIP runtime failure: RuntimeError */
+
+#define D3PM_KIND_UNIFORM   0
+#define D3PM_KIND_GAUSSIAN  1
+#define D3PM_KIND_ABSORBING 2
+
+#define D3PM_NOISE_UNIFORM     0  /* U[0,1) float32 [B,npos,K], transformed on device */
+#define D3PM_NOISE_GUMBEL      1  /* pre-transformed -log(-log u) float32 [B,npos,K]  */
+#define D3PM_NOISE_PHILOX      2  /* no tensor: Philox4x32-10 on device (seed, offset) */
+#define D3PM_NOISE_EXPONENTIAL 3  /* Exp(1) float64 [B,npos,K] (protein style)         */
+
+#define D3PM_LOSS_KL      0
+#define D3PM_LOSS_CE      1   /* cross_entropy_x_start */
+#define D3PM_LOSS_HYBRID  2
+
+const char* d3pm_last_error(void);
+int d3pm_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Transition tables
+ * --------------------------------------------------------------------- */
+
+/* One-step matrices Q_t [T,K,K] (row = from, column = to) and cumulative
+ * products Qbar_t = Q_0 ... Q_t, float64.
+ * Replaces DiscreteDiffusion.__init__ table construction,
+ * d3pm/diffusion_discrete.py:56-99 with _get_full_transition_mat :101-119,
+ * _get_transition_mat :122-154, _get_gaussian_transition_mat :156-190 and
+ * _get_absorbing_transition_mat :192-202.  bands < 0 means "None". */
+int d3pm_build_tables_f64(int kind, int K, int T, int bands, const double* betas,
+                          double* q_onestep, double* q_mats, void* stream);
+
+/* Protein-style uniform tables: Q_t = off_t * ones + norm_t * I (float32
+ * scalars promoted to float64) and their running products.
+ * Replaces Tokenizer.q_uniform_schedule + cumprod_matrix,
+ * protein_generation/utils.py:65-83 and :7-18.  off[T], norm[T] float32. */
+int d3pm_protein_uniform_tables_f64(int K, int T, const float* off, const float* norm,
+                                    double* q_onestep, double* q_bar, void* stream);
+
+/* Generic running product of T float64 [K,K] matrices with strides in elements
+ * (cumprod_matrix, protein_generation/utils.py:7-18). */
+int d3pm_cumprod_f64(int K, int T, const double* mats, long st, long sr, long sc,
+                     double* out, void* stream);
+
+/* Column-structured digest of a [T,K,K] float64 table with element strides
+ * (st, sr, sc): if, after the float32 cast the reference applies in _at
+ * (d3pm/diffusion_discrete.py:218), every column j of every matrix t has one
+ * off-diagonal value, the table is  entry(i,j) = i==j ? diag[t][j] : off[t][j].
+ * digest is float32 [T][4][K]: diag, off, log(diag+eps), log(off+eps).
+ * *violations (device int, zeroed by the caller) counts entries that break the
+ * structure; the dense path must be used when it is non-zero. */
+int d3pm_digest_f32(const double* table, long st, long sr, long sc, int T, int K, float eps,
+                    float* digest, int* violations, void* stream);
+
+/* Same test in float64 with a relative tolerance; digest float64 [T][2][K]:
+ * diag, off.  For the protein-style kernels, which compute in float64
+ * (protein_generation/losses.py:65). */
+int d3pm_digest_f64(const double* table, long st, long sr, long sc, int T, int K, double rtol,
+                    double* digest, int* violations, void* stream);
+
+/* float64 -> float32 copy of a strided [T,K,K] table into a contiguous one
+ * (the `a.to(dtype=float32)` of _at/_at_onehot, :218,:242, done once). */
+int d3pm_table_to_f32(const double* table, long st, long sr, long sc, int T, int K,
+                      float* out, void* stream);
+
+/* Float32 view of the tables a kernel needs.  `structured` selects the digest
+ * path (O(K) per token) or the dense path (gathers + K x K contraction). */
+typedef struct d3pm_tables_f32 {
+  int K, T;
+  int structured;
+  float eps;                 /* 1e-6, DiscreteDiffusion.eps (:49) */
+  const float* qbar_digest;  /* [T][4][K] of q_mats                       */
+  const float* qone_digest;  /* [T][4][K] of the one-step Q_t             */
+  const float* qbar;         /* [T][K][K] q_mats, float32 (dense only)    */
+  const float* qoneT;        /* [T][K][K] transpose_q_onestep_mats (dense)*/
+  const float* qbarT;        /* [T][K][K] q_mats transposed (dense, for the backward contraction) */
+} d3pm_tables_f32;
+
+/* Float64 view for the protein-style kernels (structured only). */
+typedef struct d3pm_tables_f64 {
+  int K, T;
+  const double* qbar_digest; /* [T][2][K] of Q_bar */
+  const double* qone_digest; /* [T][2][K] of Q_t   */
+} d3pm_tables_f64;
+
+/* ------------------------------------------------------------------------
+ * Image-style process (d3pm/diffusion_discrete.py)
+ * --------------------------------------------------------------------- */
+
+/* q_probs (:250-263): out[b,p,:] = float32(q_mats)[t_b, x0[b,p], :]. */
+int d3pm_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes,
+                 int B, long npos, float* out, void* stream);
+
+/* q_sample (:266-285): x_t = argmax_j(log(q_probs + eps) + gumbel), first
+ * maximal index; x_t int64.  noise_kind UNIFORM / GUMBEL / PHILOX. */
+int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes,
+                  int B, long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
+                  int64_t* x_t, void* stream);
+
+/* q_posterior_logits (:312-336).  x_start_is_logits == 0: x_start is a token
+ * array; != 0: float32 logits [B,npos,ld].  out float32 [B,npos,K].  With
+ * x_start_is_logits this is also p_logits (:339-381) for model_output='logits',
+ * model_prediction='x_start' (the where(t==0) of :362 coincides with :336). */
+int d3pm_q_posterior_logits(const d3pm_tables_f32* tb, const void* x_start, int x_start_is_logits, long ld,
+                            int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
+                            int B, long npos, float* out, void* stream);
+
+/* Workspace (bytes) d3pm_hybrid_loss needs for B x npos x K. */
+size_t d3pm_hybrid_loss_workspace(int B, long npos, int K);
+
+/* vb_terms_bpd (:462-489) + cross_entropy_start (:527-542) + the combination
+ * of training_losses (:558-582), and the gradient of
+ * sum_b grad_scale*grad_out[b]*loss[b] with respect to the denoiser logits, in
+ * one pass (grad_scale = 1/B bakes in the `.mean()` of the training loop).
+ *   logits  float32 [B,npos,ld] (the model_fn output, 'logits'/'x_start' mode)
+ *   grad_out float32 [B] upstream gradient per sample, or NULL for all ones
+ *   vb, ce, loss  float32 [B] (any may be NULL)
+ *   dlogits float32 [B,npos,ld] or NULL (forward only); columns >= K get 0
+ *   workspace: d3pm_hybrid_loss_workspace() bytes, contents irrelevant. */
+int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld,
+                     const void* x0, int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
+                     int B, long npos, int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out,
+                     float* vb, float* ce, float* loss, float* dlogits,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* In-place per-sample rescale g[b,:] *= upstream[b]/baked; blocks whose
+ * upstream[b] equals `baked` exactly touch nothing.  Backward of the autograd
+ * node when the upstream gradient differs from the scale d3pm_hybrid_loss /
+ * d3pm_lvb_loss baked in. */
+int d3pm_scale_rows(float* g, const float* upstream, float baked, int B, long row_elems, void* stream);
+
+/* p_sample (:384-403): sample = argmax_j(p_logits + [t!=0]*gumbel) int64;
+ * probs (may be NULL) = softmax(logits) float32 [B,npos,K]. */
+int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x_t, int xt_bytes,
+                  const void* t, int t_bytes, int B, long npos, const float* noise, int noise_kind,
+                  uint64_t seed, uint64_t offset, int64_t* sample, float* probs, void* stream);
+
+/* prior_bpd (:492-524): KL(q(x_{T-1}|x0) || stationary)/ln2 averaged over
+ * positions; stationary is uniform, or one-hot at K/2 when absorbing != 0.
+ * out float32 [B]; workspace as for d3pm_hybrid_loss. */
+int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
+                   int absorbing, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Protein-style process (protein_generation/)
+ * --------------------------------------------------------------------- */
+
+/* Batched sample_transition_matrix (utils.py:44-52) as the collaters use it
+ * (dataset.py:234-242): x_t[b,p] = argmax_j(Qbar[t_b][x0,j] / E_j), the
+ * CPU torch.multinomial draw.  expo float64 [B,npos,K] or NULL (Philox).
+ * probs (may be NULL) float64 [B,npos,K] = the q_x the collater returns. */
+int d3pm_corrupt(const d3pm_tables_f64* tb, const int64_t* x0, const int64_t* t, int B, long npos,
+                 const double* expo, uint64_t seed, uint64_t offset, int64_t* x_t, double* probs,
+                 void* stream);
+
+/* Workspace (bytes) d3pm_lvb_loss needs for B x npos x K. */
+size_t d3pm_lvb_loss_workspace(int B, long npos, int K);
+
+/* D3PMLVBLoss.forward (losses.py:48-93) / D3PMLVBLossMSA.forward (:120-155)
+ * per batch element.  msa = 0: single sequences; msa = D > 0: MSAs of depth D
+ * (npos = D*L): the posterior denominator comes from Qbar[t-1] (:148) and the
+ * t==tmax term is normalised by D, the leading size of q[i] (:130).  Also the gradient of
+ * grad_scale * sum_b per_seq[b] with respect to the predictions.
+ *   pred float32 [B,npos,ld], ld = n_tokens >= K (t==1 branch uses all ld)
+ *   q    float64 [B,npos,K] forward probabilities, read only where t==tmax
+ *   per_seq float64 [B];  dpred float32 [B,npos,ld] or NULL
+ *   workspace: d3pm_lvb_loss_workspace() bytes, contents irrelevant. */
+int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                  const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax,
+                  int msa, double grad_scale, double* per_seq, float* dpred,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Reverse step of generate_d3pm (generate.py:28-40): x_{t-1} =
+ * argmax_j(P_j / E_j), P the normalised p-squared marginal.  t int64 [B]. */
+int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,
+                          const int64_t* t, int B, long npos, const double* expo, uint64_t seed,
+                          uint64_t offset, int64_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3PM_HIP_H */

@@ -1,0 +1,258 @@
+"""GPU parity of the image-style process: HIP kernels (through the facade and
+the C ABI) against the golden vectors captured from the reference and against
+the CPU oracle on seeded inputs.
+
+Bars: integer outputs (sampled tokens) bit-exact; float32 logits, losses and
+gradients within 1e-5 relative (absolute floor stated per check)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import image_style as im
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 1e-5
+# Absolute floor for per-sample losses (bits/dim).  A KL term is a sum of
+# differences of log-probabilities of magnitude up to ~14, each carrying float32
+# rounding (6e-8 relative), so the reference's own float32 value of a KL that
+# is close to zero (late timesteps: 1e-4 and below) is only defined to a few
+# 1e-7 absolute.  Losses of ordinary size are held to RTOL.
+LOSS_ATOL = 5e-7
+# Table entries are probabilities in [0,1] built in float64; entries such as
+# diag = 1 - rowsum carry an absolute rounding of a few 1e-16 whatever their size.
+TABLE_ATOL = 1e-15
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import d3pm_amd
+    return d3pm_amd
+
+
+def T_(a, dev=DEV):
+    return torch.from_numpy(np.array(a)).to(dev)
+
+
+def make(pkg, g, kind, bits, bands=None, lam=0.001, loss_type="hybrid"):
+    return pkg.DiscreteDiffusion(betas=torch.from_numpy(g["betas"]), transition_mat_type=kind, num_bits=bits,
+                                 transition_bands=bands, model_prediction="x_start", model_output="logits",
+                                 loss_type=loss_type, hybrid_coeff=lam, device=DEV)
+
+
+def close(a, b, rtol=RTOL, atol=1e-6, what=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def check_tokens(got, want, margin, what):
+    """Bit-exact, except where the reference's own top-2 margin is below
+    float32 resolution of the logits (none in the committed fixtures)."""
+    got = got.cpu().numpy()
+    bad = got != want
+    if bad.any():
+        assert (margin[bad] < 1e-5).all(), f"{what}: {bad.sum()} tokens differ with margin >= 1e-5"
+    assert bad.sum() == 0, f"{what}: {bad.sum()} near-tie tokens differ (margins {margin[bad]})"
+
+
+def check_downstream(d, g, own_tables=False):
+    """own_tables: the process runs on tables it built itself, which differ from
+    the reference's by float64 rounding (1e-16 absolute), so gathered
+    probabilities are compared to that accuracy instead of bit for bit."""
+    x0, t = T_(g["x0"]), T_(g["t"])
+    noise, logits, noise2, w = T_(g["noise"]), T_(g["logits"]), T_(g["noise2"]), T_(g["w"])
+    if own_tables:
+        np.testing.assert_allclose(d.q_probs(x0, t).cpu().numpy(), g["q_probs"], rtol=1e-6, atol=1e-15)
+    else:
+        np.testing.assert_array_equal(d.q_probs(x0, t).cpu().numpy(), g["q_probs"])
+    x_t = d.q_sample(x0, t, noise)
+    assert x_t.dtype == torch.int64 and x_t.shape == x0.shape
+    check_tokens(x_t, g["x_t"], g["q_sample_margin"], "q_sample(uniform noise)")
+    gum = im.gumbel_from_uniform(torch.from_numpy(g["noise"])).to(DEV)
+    check_tokens(d.q_sample(x0, t, gum, noise_kind="gumbel"), g["x_t"], g["q_sample_margin"], "q_sample(gumbel)")
+    x_t = T_(g["x_t"])
+    close(d.q_posterior_logits(x0, x_t, t, x_start_logits=False), g["post_true"], atol=1e-5, what="post_true")
+    close(d.q_posterior_logits(logits, x_t, t, x_start_logits=True), g["post_model"], atol=1e-5, what="post_model")
+    ml, px0 = d.p_logits(lambda x, tt: logits, x=x_t, t=t)
+    close(ml, g["p_logits"], atol=1e-5, what="p_logits")
+    assert px0 is logits
+    vb, _ = d.vb_terms_bpd(lambda x, tt: logits, x_start=x0, x_t=x_t, t=t)
+    close(vb, g["vb"], atol=LOSS_ATOL, what="vb")
+    close(d.cross_entropy_start(x0, logits), g["ce"], atol=1e-7, what="ce")
+    for lt in ("hybrid", "kl", "cross_entropy_x_start"):
+        d.loss_type = lt
+        lg = logits.clone().requires_grad_(True)
+        # replay of training_losses with the recorded t and noise
+        losses = d.training_losses(lambda x, tt: lg, x_start=x0, t=t, noise=noise)
+        close(losses, g["losses_" + lt], atol=LOSS_ATOL, what="losses " + lt)
+        (gr,) = torch.autograd.grad((losses * w).sum(), lg)
+        ref = g["grad_w_" + lt]
+        close(gr, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what="grad " + lt)
+    d.loss_type = "hybrid"
+    s, probs = d.p_sample(lambda x, tt: logits, x=x_t, t=t, noise=noise2)
+    check_tokens(s, g["p_sample"], g["p_sample_margin"], "p_sample")
+    close(probs, g["p_sample_probs"], atol=1e-7, what="p_sample probs")
+    if g["prior_bpd"].size:
+        close(d.prior_bpd(x0), g["prior_bpd"], rtol=1e-4, atol=LOSS_ATOL, what="prior_bpd")
+
+
+def test_uniform_k32_golden(pkg):
+    g = golden("image_uniform_k32")
+    d = make(pkg, g, "uniform", 5)
+    ts = g["slice_t"]
+    np.testing.assert_allclose(d.q_mats.cpu().numpy()[ts], g["q_mats_slices"], rtol=1e-12, atol=TABLE_ATOL)
+    np.testing.assert_allclose(d.transpose_q_onestep_mats.cpu().numpy()[ts], g["qT_onestep_slices"], rtol=1e-12, atol=TABLE_ATOL)
+    assert d.tables().structured
+    check_downstream(d, g)
+    # the same through the dense kernels
+    d.force_dense = True
+    assert not d.tables().structured
+    check_downstream(d, g)
+
+
+def test_uniform_cosine_tables(pkg):
+    g = golden("image_uniform_k32_cosine_tables")
+    d = make(pkg, g, "uniform", 5)
+    np.testing.assert_allclose(d.q_mats.cpu().numpy()[g["slice_t"]], g["q_mats_slices"], rtol=1e-12, atol=TABLE_ATOL)
+
+
+def test_absorbing_k32_golden(pkg):
+    g = golden("image_absorbing_k32")
+    d = make(pkg, g, "absorbing", 5)
+    ts = g["slice_t"]
+    np.testing.assert_allclose(d.q_mats.cpu().numpy()[ts], g["q_mats_slices"], rtol=1e-12, atol=TABLE_ATOL)
+    np.testing.assert_allclose(d.transpose_q_onestep_mats.cpu().numpy()[ts], g["qT_onestep_slices"], rtol=1e-12, atol=TABLE_ATOL)
+    assert d.tables().structured
+    check_downstream(d, g)
+    d.force_dense = True
+    check_downstream(d, g)
+
+
+@pytest.mark.parametrize("name,kind,bands", [("gaussian_k16_full", "gaussian", None),
+                                             ("gaussian_k16_b5", "gaussian", 5),
+                                             ("uniform_k16_b3", "uniform", 3)])
+def test_small_dense_tables_golden(pkg, name, kind, bands):
+    g = golden("image_" + name)
+    d = make(pkg, g, kind, 4, bands)
+    np.testing.assert_allclose(d.q_mats.cpu().numpy(), g["q_mats"], rtol=1e-12, atol=TABLE_ATOL)
+    np.testing.assert_allclose(d.transpose_q_onestep_mats.cpu().numpy(), g["qT_onestep"], rtol=1e-12, atol=TABLE_ATOL)
+    assert not d.tables().structured
+    # downstream on the reference's own tables, so that table rounding cannot move a token
+    d.q_mats = T_(g["q_mats"])
+    d.transpose_q_onestep_mats = T_(g["qT_onestep"])
+    check_downstream(d, g)
+
+
+def test_gaussian_k256_golden(pkg):
+    g = golden("image_gaussian_k256")
+    d = make(pkg, g, "gaussian", 8)
+    ts = g["slice_t"]
+    np.testing.assert_allclose(d.q_mats.cpu().numpy()[ts], g["q_mats_slices"], rtol=1e-11, atol=TABLE_ATOL)
+    np.testing.assert_allclose(d.transpose_q_onestep_mats.cpu().numpy()[ts], g["qT_onestep_slices"], rtol=1e-12,
+                               atol=TABLE_ATOL)
+    assert not d.tables().structured
+    check_downstream(d, g, own_tables=True)
+
+
+def test_seeded_against_oracle_odd_shapes(pkg):
+    """K not a multiple of 4, int32 tokens, 2-D data, B=1 and npos=1."""
+    for bits, B, shape in ((3, 5, (7,)), (3, 1, (1,)), (6, 3, (5, 2)), (7, 2, (3, 3, 1))):
+        K = 2 ** bits
+        betas = pkg.generate_betas(0.02, 0.5, 12, "linear")
+        for kind in ("uniform", "absorbing", "gaussian"):
+            d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                                      model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                      hybrid_coeff=0.01, device=DEV)
+            p = im.build_process(betas, kind, bits, None, hybrid_coeff=0.01)
+            gen = torch.Generator().manual_seed(bits * 100 + B)
+            # the oracle follows the reference's 4-D data convention
+            x0 = torch.randint(0, K, (B,) + shape, generator=gen, dtype=torch.int32)
+            x0_4d = x0.reshape(B, -1, 1, 1)
+            t = torch.randint(0, 12, (B,), generator=gen, dtype=torch.int32)
+            t[0] = 0
+            noise = torch.rand(x0_4d.shape + (K,), generator=gen)
+            logits = torch.randn(x0_4d.shape + (K,), generator=gen)
+            xt_ref = im.forward_sample(p, x0_4d, t, noise)
+            lg_ref = logits.clone().requires_grad_(True)
+            loss_ref = im.losses_given_xt(p, lg_ref, x0_4d, xt_ref, t)
+            loss_ref.sum().backward()
+            xt = d.q_sample(x0.to(DEV), t.to(DEV), noise.reshape(x0.shape + (K,)).to(DEV))
+            assert torch.equal(xt.cpu().reshape(xt_ref.shape), xt_ref)
+            lg = logits.reshape(x0.shape + (K,)).to(DEV).requires_grad_(True)
+            loss = d.training_losses(lambda x, tt: lg, x_start=x0.to(DEV), t=t.to(DEV),
+                                     noise=noise.reshape(x0.shape + (K,)).to(DEV))
+            loss.sum().backward()
+            close(loss, loss_ref.detach().numpy(), atol=1e-6, what=f"loss {kind} K={K}")
+            ref = lg_ref.grad.numpy().reshape(lg.shape)
+            close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
+
+
+def test_empty_batch_and_errors(pkg):
+    betas = pkg.generate_betas(0, 0, 10, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.001, device=DEV)
+    x0 = torch.zeros((0, 4, 1, 1), dtype=torch.int64, device=DEV)
+    t = torch.zeros((0,), dtype=torch.int32, device=DEV)
+    assert d.q_sample(x0, t).shape == (0, 4, 1, 1)
+    assert d.q_probs(x0, t).shape == (0, 4, 1, 1, 8)
+    with pytest.raises(AssertionError):
+        d.q_sample(torch.zeros((2, 4), dtype=torch.int64, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV),
+                   torch.rand(2, 4, 7, device=DEV))
+    d.loss_type = "nope"
+    with pytest.raises(NotImplementedError):
+        d.training_losses(lambda x, tt: None, x_start=torch.zeros((2, 4), dtype=torch.int64, device=DEV))
+    d.model_output = "xyz"
+    d.loss_type = "hybrid"
+    with pytest.raises(NotImplementedError):
+        d.p_logits(lambda x, tt: None, x=torch.zeros((2, 4), dtype=torch.int64, device=DEV),
+                   t=torch.zeros(2, dtype=torch.int32, device=DEV))
+
+
+def test_full_size_properties(pkg):
+    """The benchmark configuration (B=256, L=512, K=32, T=500): properties that
+    hold at any size, plus a slice checked against the oracle."""
+    B, L, K, T = 256, 512, 32, 500
+    betas = pkg.generate_betas(0, 0, T, "jsd")
+    torch.manual_seed(3)
+    for kind in ("uniform", "absorbing"):
+        d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=5, transition_bands=None,
+                                  model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                  hybrid_coeff=0.001, device=DEV)
+        x0 = torch.randint(0, K, (B, L, 1, 1), device=DEV)
+        t = torch.randint(0, T, (B,), dtype=torch.int32, device=DEV)
+        t[:3] = torch.tensor([0, 1, T - 1], dtype=torch.int32)
+        noise = torch.rand(B, L, 1, 1, K, device=DEV)
+        x_t = d.q_sample(x0, t, noise)
+        assert int(x_t.min()) >= 0 and int(x_t.max()) < K
+        # same noise -> same tokens; Philox noise is repeatable under a seed
+        assert torch.equal(x_t, d.q_sample(x0, t, noise))
+        torch.manual_seed(9); a = d.q_sample(x0, t)
+        torch.manual_seed(9); b = d.q_sample(x0, t)
+        assert torch.equal(a, b)
+        # t = 0 for uniform jsd has beta_0 = 1/T: most tokens survive
+        assert (x_t[0] == x0[0]).float().mean() > 0.9
+        lg = torch.randn(B, L, 1, 1, K, device=DEV, requires_grad=True)
+        vb, _ = d.vb_terms_bpd(lambda x, tt: lg, x_start=x0, x_t=x_t, t=t)
+        assert bool((vb >= -1e-6).all()), "KL terms must be non-negative"
+        loss = d.training_losses(lambda x, tt: lg, x_start=x0, t=t, noise=noise)
+        loss.mean().backward()
+        g = lg.grad
+        # gradients of softmax-parameterised losses sum to zero over classes
+        assert float(g.sum(-1).abs().max()) < 1e-6 * float(g.abs().max()) * K + 1e-12
+        # a prediction that is one-hot on x0 drives the KL to (almost) zero
+        sharp = torch.nn.functional.one_hot(x0, K).float() * 60.0
+        vb0, _ = d.vb_terms_bpd(lambda x, tt: sharp, x_start=x0, x_t=x_t, t=t)
+        assert float(vb0.max()) < 1e-3
+        # oracle on a slice
+        sl = slice(0, 6)
+        p = im.build_process(betas, kind, 5, None, hybrid_coeff=0.001)
+        lg_ref = lg.detach()[sl].cpu().clone().requires_grad_(True)
+        xt_ref = im.forward_sample(p, x0[sl].cpu(), t[sl].cpu(), noise[sl].cpu())
+        assert torch.equal(xt_ref, x_t[sl].cpu())
+        loss_ref = im.losses_given_xt(p, lg_ref, x0[sl].cpu(), xt_ref, t[sl].cpu())
+        close(loss[sl], loss_ref.detach().numpy(), atol=LOSS_ATOL)
+        (loss_ref.sum() / B).backward()
+        ref = lg_ref.grad.numpy()
+        close(g[sl], ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
