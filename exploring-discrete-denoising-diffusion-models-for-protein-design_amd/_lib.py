@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libd3pm_hip.so")
+LIB_PATH = os.environ.get("D3PM_LIB", os.path.join(_HERE, "libd3pm_hip.so"))
 
 OK, EINVAL, EUNSUPPORTED, EHIP = 0, 1, 2, 3
 KIND = {"uniform": 0, "gaussian": 1, "absorbing": 2}

@@ -478,8 +478,8 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       hipLaunchKernelGGL((k_dense_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL>), grid, block,
                          dense_lds_bytes<L>(tb->K, false), s, a, e);
     D3PM_LAUNCH_CHECK("k_dense_tile<LOSS>");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, e.part, B, a.chunks, npos, loss_type,
-                       hybrid_coeff, vb, ce, loss);
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{vb, ce, loss, e.part}, B,
+                       a.chunks, npos, loss_type, hybrid_coeff, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;
   });
@@ -518,8 +518,8 @@ static int dense_prior(const d3pm_tables_f32* tb, const void* x0, int tok_bytes,
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_dense_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_dense_prior");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, D3PM_LOSS_KL,
-                       0.0f, out, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{out, nullptr, nullptr, part}, B,
+                       a.chunks, npos, D3PM_LOSS_KL, 0.0f, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;
   });

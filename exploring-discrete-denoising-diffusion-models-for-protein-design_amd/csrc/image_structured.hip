@@ -11,6 +11,8 @@
 // inside lane groups.
 #include "layout.h"
 
+#include <cstdlib>
+
 namespace d3pm {
 
 constexpr float LN2 = 0.693147180559945309417f;
@@ -175,145 +177,284 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_logits(ImgArgs a, const flo
 }
 
 // ------------------------------------------------------------------ fused hybrid loss, forward + backward
-// Per token (t > 0), with pi = softmax(z), A the column x_t of Q_t, Qm = Qbar_{t-1}:
-//   f2 = pi Qm,  m = log(A+eps) + log(f2+eps),  tl = log(A+eps) + log(Qm[x0,:]+eps)
-//   kl = sum softmax(tl+eps) (lsm(tl+eps) - lsm(m+eps)),  ce = -lsm(z)[x0]
-//   d kl/d m = softmax(m) - softmax(tl);  chain through f2 and the softmax of z.
-// t == 0: kl is replaced by ce.  Partial sums per workgroup go to `part`
-// ([B][chunks][2]: vb numerator, ce numerator), combined by k_loss_finalize in a
-// fixed order so the result does not depend on scheduling.
+// Per token (t > 0), with pi = softmax(z), a = column x_t of Q_t (+eps),
+// Qm = Qbar_{t-1}, b = row x0 of Qm (+eps), f2 = pi Qm + eps:
+//   p_model ~ a .* f2,   q_true ~ a .* b           (normalised over classes: Zm, Zt)
+//   kl = sum_j q_j log(b_j / f2_j) + log(Zm / Zt),   ce = -log_softmax(z)[x0]
+// which is the reference's softmax(log(a)+log(.)+eps) / log_softmax difference
+// (d3pm/utils.py:54-58) with exp(log(x)) folded to x; logs are taken in base 2
+// because the result is wanted in bits.  t == 0: kl is replaced by ce.
+//
+// Column structure makes a and b constant over classes except at x_t
+// (a = a_o + da) and x0 (b = boe + bdo), so every class is first treated as a
+// generic one (a_o, boe_j) inside the lanes, and the two special classes are
+// corrected per token with scalars:
+//   Zt  = a_o (sum_j boe_j + bdo_x0) + da b_xt,          b_xt = boe_xt + [x0==xt] bdo_xt
+//   Zm  = a_o sum_j f2_j + da f2_xt
+//   kl Zt = a_o S1 - a_o boe_x0 lg(boe_x0/f2_x0) + a_x0 b_x0 lg(b_x0/f2_x0)
+//           + [x0!=xt] da boe_xt lg(boe_xt/f2_xt),        S1 = sum_j boe_j lg(boe_j/f2_j)
+//   d kl / d f2_j = w a_j (1/Zm - b_j/(Zt f2_j)) = A1 - A2 boe_j/f2_j  (+ d_x0 at x0, + d_xt at xt)
+// and the chain through f2 = boe + bdo pi and the softmax of z is
+//   g pi_j = R + gf2_j bdo_j,  R = sum_j gf2_j bo_j,  gz_j = pi_j (g pi_j - <pi, g pi>) + w_ce (pi_j - [j==x0]).
+// Per class: one exp2, one rcp, one log2 and ~20 other VALU operations; four
+// rounds of lane-group reductions per token.  The values at x0 and x_t are read
+// again from the row (an L1 hit) instead of being extracted across lanes.
+//
+// Rows move through a rolling pipeline of PIPE slots per lane group (64 bytes
+// per lane in flight), the first of them requested before the
+// timestep -> digest dependency chain.
+//
+// Reduction over positions: lanes by butterfly, waves through LDS in index
+// order, then either directly to vb/ce/loss (one workgroup per batch element)
+// or to `part` ([B][chunks][2]) for k_loss_finalize; the order is fixed, so the
+// result does not depend on scheduling.
+constexpr float LOG2E = 1.44269504088896340736f;
+// rows in flight per lane group: 64 bytes per lane whatever the layout
+template <class L> constexpr int pipe_depth() { return L::V >= 8 ? 2 : 4; }
+template <class L> constexpr int loss_max_threads() { return L::V >= 8 ? 512 : 1024; }
+constexpr int MAX_WAVES = 16;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+struct LossOut {
+  float* vb; float* ce; float* loss;   // [B], any may be null (chunks == 1)
+  float* part;                         // [B][chunks][2] (chunks > 1)
+};
+
+__device__ __forceinline__ void write_losses(const LossOut& o, int b, float svb, float sce, long npos, int loss_type,
+                                             float hybrid_coeff) {
+  // sums arrive in bits
+  const float v = svb / (float)npos, c_ = sce / (float)npos;
+  if (o.vb) o.vb[b] = v;
+  if (o.ce) o.ce[b] = c_;
+  if (o.loss) o.loss[b] = loss_type == D3PM_LOSS_KL ? v : (loss_type == D3PM_LOSS_CE ? c_ : v + hybrid_coeff * c_);
+}
+
 template <class L, bool GRAD>
-__global__ __launch_bounds__(BLOCK) void k_hybrid_loss(ImgArgs a, const float* __restrict__ logits, long ld,
-                                                       int loss_type, float hybrid_coeff, float grad_scale,
-                                                       const float* __restrict__ grad_out, float* __restrict__ part,
-                                                       float* __restrict__ dlogits) {
-  __shared__ float red[2 * (BLOCK / 64)];
+__global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
+    ImgArgs a, const float* __restrict__ logits, long ld, int loss_type, float hybrid_coeff, float grad_scale,
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
+  __shared__ float red[2 * MAX_WAVES];
+  // by class: column of Q_t (diag+eps, off+eps), Qbar_{t-1} (diag-off, off+eps)
+  __shared__ float s_ad[256], s_ao[256], s_bdo[256], s_boe[256];
+  constexpr int PIPE = pipe_depth<L>();
   const int K = a.tb.K;
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const unsigned tpp = blockDim.x / L::G;     // tokens per pass
+  // Rows of this batch element through wave-uniform bases and 32-bit byte
+  // offsets (the host checks npos * ld < 2^30).  Tokens are non-negative and
+  // below 2^31, so the low dword of an int64 token is the token.
+  const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * ld);
+  char* __restrict__ drow = GRAD ? (char*)(dlogits + (size_t)b * a.npos * ld) : nullptr;
+  const char* __restrict__ x0row = (const char*)a.x0 + (size_t)b * a.npos * a.x0_bytes;
+  const char* __restrict__ xtrow = (const char*)a.xt + (size_t)b * a.npos * a.xt_bytes;
+  const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
+  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
+  const unsigned pbeg = (unsigned)(chunk * a.chunk_pos) + slot;
+  const unsigned row_bytes = (unsigned)ld * 4u;
+
+  float zz[PIPE][L::V];
+  int x0s[PIPE], xts[PIPE];
+  auto issue_load = [&](int u, unsigned pos) {
+    load_slots_off<L>(lrow, pos * row_bytes, g, K, -INFINITY, zz[u]);
+    x0s[u] = *reinterpret_cast<const int*>(x0row + (pos << x0sh));
+    xts[u] = *reinterpret_cast<const int*>(xtrow + (pos << xtsh));
+  };
+#pragma unroll
+  for (int u = 0; u < PIPE; ++u) {
+    const unsigned pos = pbeg + u * tpp;
+    if (pos < p1) issue_load(u, pos);
+  }
+  // The logits of a token's two special classes (x0, x_t) are read again from its
+  // row, one stage ahead of use and before the previous stage's stores, so that
+  // waiting for them never waits for a store.
+  float sp0[PIPE], spt[PIPE];
+  auto issue_special = [&](int u, unsigned pos) {
+    sp0[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)x0s[u]));
+    spt[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)xts[u]));
+  };
+  if (pbeg < p1) issue_special(0, pbeg);
+
   const int t = load_tok(a.t, b, a.t_bytes);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
-  Post<L> P;
-  if (need_post) load_post<L>(a.tb, t, g, P);
+  // per-class constants of Qbar_{t-1} for this lane's slots, and their sums over all classes
+  float bdo[L::V], boe[L::V], bo[L::V];
+  float sum_boe = 0, sum_bo = 0;
+  if (need_post) {
+    float bd[L::V];
+    load_digest<L>(a.tb.qbar_digest, t - 1, 0, K, g, bd);
+    load_digest<L>(a.tb.qbar_digest, t - 1, 1, K, g, bo);
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const bool ok = L::VEC || L::cls(g, v) < K;
+      bdo[v] = ok ? bd[v] - bo[v] : 0.0f;
+      boe[v] = ok ? bo[v] + eps : 1.0f;        // masked slots: f2 = 1, log 1 = 0
+      bo[v] = ok ? bo[v] : 0.0f;
+      sum_boe += ok ? boe[v] : 0.0f;
+      sum_bo += bo[v];
+    }
+    sum_boe = group_sum<L::G>(sum_boe);
+    sum_bo = group_sum<L::G>(sum_bo);
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+      s_ad[j] = dg(a.tb.qone_digest, t, 0, K)[j] + eps;
+      s_ao[j] = dg(a.tb.qone_digest, t, 1, K)[j] + eps;
+      const float d = dg(a.tb.qbar_digest, t - 1, 0, K)[j], o = dg(a.tb.qbar_digest, t - 1, 1, K)[j];
+      s_bdo[j] = d - o;
+      s_boe[j] = o + eps;
+    }
+    __syncthreads();
+  }
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
   // weights of d(vb)/dz and d(ce)/dz in the requested loss
   const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
   const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
-  float acc_vb = 0, acc_ce = 0;
-  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
-  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
-    const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
-    float z[L::V], pi[L::V], zmax, zsum;
-    load_slots<L>(logits + n * ld, g, K, -INFINITY, z);
-    group_softmax<L>(z, pi, zmax, zsum);
-    float zx0 = 0;
+  float acc_vb = 0, acc_ce = 0;          // per-lane partial sums, in bits; lane 0 of a group carries the token
+  for (unsigned pos0 = pbeg; pos0 < p1; pos0 += PIPE * tpp) {
 #pragma unroll
-    for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0) ? z[v] : 0.0f;
-    zx0 = group_sum<L::G>(zx0);
-    const float ce = (zmax + logf(zsum)) - zx0;
-    float gz[L::V];
-    float vb;
-    if (!need_post) {
-      vb = ce;
-      if constexpr (GRAD) {
-        const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
+    for (int u = 0; u < PIPE; ++u) {
+      const unsigned pos = pos0 + u * tpp;
+      if (pos >= p1) break;              // whole lane groups leave together
+      const int x0 = x0s[u];
+      const int xt = xts[u];
+      const float z_x0 = sp0[u], z_xt = spt[u];
+      float z[L::V];
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) gz[v] = w * (pi[v] - ((L::cls(g, v) == x0) ? 1.0f : 0.0f));
+      for (int v = 0; v < L::V; ++v) z[v] = zz[u][v];
+      {                                  // special classes of the next stage, then refill this stage's slot
+        const unsigned nxt1 = pos + tpp, nxt = pos + PIPE * tpp;
+        if (nxt1 < p1) issue_special((u + 1) % PIPE, nxt1);
+        if (nxt < p1) issue_load(u, nxt);
       }
-    } else {
-      const int xt = load_tok(a.xt, n, a.xt_bytes);
-      const float l1d = dg(a.tb.qone_digest, t, 2, K)[xt], l1o = dg(a.tb.qone_digest, t, 3, K)[xt];
-      float f2e[L::V], lm[L::V], tl[L::V];
-      float mmax = -INFINITY, tmax = -INFINITY;
+      // ---- round 1, 2: softmax of z
+      float m = z[0];
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) {
-        const int c = L::cls(g, v);
-        const bool ok = L::VEC || c < K;
-        const float l1 = (c == xt) ? l1d : l1o;
-        f2e[v] = fmaf(P.bd[v] - P.bo[v], pi[v], P.bo[v]) + eps;
-        lm[v] = ok ? (l1 + logf(f2e[v])) + eps : -INFINITY;
-        tl[v] = ok ? (l1 + ((c == x0) ? P.lbd[v] : P.lbo[v])) + eps : -INFINITY;
-        mmax = fmaxf(mmax, lm[v]);
-        tmax = fmaxf(tmax, tl[v]);
-      }
-      mmax = group_max<L::G>(mmax);
-      tmax = group_max<L::G>(tmax);
-      float em[L::V], et[L::V], sm = 0, st = 0;
+      for (int v = 1; v < L::V; ++v) m = fmaxf(m, z[v]);
+      m = group_max<L::G>(m);
+      const float mneg = -m * LOG2E;
+      float pi[L::V], s = 0;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) {
-        em[v] = expf(lm[v] - mmax); sm += em[v];
-        et[v] = expf(tl[v] - tmax); st += et[v];
-      }
-      sm = group_sum<L::G>(sm);
-      st = group_sum<L::G>(st);
-      const float lsm_off = mmax + logf(sm), lst_off = tmax + logf(st);
-      const float ism = 1.0f / sm, ist = 1.0f / st;
-      float kl = 0;
+      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2(fmaf(z[v], LOG2E, mneg)); s += pi[v]; }
+      s = group_sum<L::G>(s);
+      const float inv = fast_rcp(s);
+      const float ce_bits = fmaf(m - z_x0, LOG2E, fast_log2(s));     // -log2 softmax(z)[x0]
+      const float tok = (g == 0) ? 1.0f : 0.0f;
+      acc_ce = fmaf(tok, ce_bits, acc_ce);
+      const int d0 = x0 - L::cls(g, 0), dt = xt - L::cls(g, 0);       // slot of x0 / x_t in this lane, if any
+      constexpr int CS = L::VEC ? 1 : L::G;                           // class stride between slots
+      float gz[L::V];
+      if (!need_post) {
+        acc_vb = fmaf(tok, ce_bits, acc_vb);
+        if constexpr (GRAD) {
+          const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
+          const float wi = w * inv;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) {
-        const bool ok = L::VEC || L::cls(g, v) < K;
-        const float q = et[v] * ist;
-        kl += ok ? q * ((tl[v] - lst_off) - (lm[v] - lsm_off)) : 0.0f;
-      }
-      vb = group_sum<L::G>(kl);
-      if constexpr (GRAD) {
-        float gf2[L::V], R = 0, dot = 0;
+          for (int v = 0; v < L::V; ++v) gz[v] = fmaf(pi[v], wi, (d0 == v * CS) ? -w : 0.0f);
+        }
+      } else {
+        const float a_d = s_ad[xt], a_o = s_ao[xt], da = a_d - a_o;
+        const float bdo_x0 = s_bdo[x0], boe_x0 = s_boe[x0], bdo_xt = s_bdo[xt], boe_xt = s_boe[xt];
+        const float same = (x0 == xt) ? 1.0f : 0.0f;
+        // ---- round 3: generic-class sums
+        float pr[L::V], Sf = 0, Rp = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
-          const float gm = (em[v] * ism - et[v] * ist) * w_vb;
-          gf2[v] = gm / f2e[v];
-          R += gf2[v] * P.bo[v];
+          pi[v] *= inv;
+          const float f2 = fmaf(bdo[v], pi[v], boe[v]);
+          pr[v] = boe[v] * fast_rcp(f2);                // boe_j / f2_j
+          Sf += (L::VEC || L::cls(g, v) < K) ? f2 : 0.0f;
+          if constexpr (GRAD) Rp = fmaf(pr[v], bo[v], Rp);
         }
-        R = group_sum<L::G>(R);
-        float gpi[L::V];
+        Sf = group_sum<L::G>(Sf);
+        if constexpr (GRAD) Rp = group_sum<L::G>(Rp);
+        // special classes
+        const float pi_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)) * inv, pi_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg)) * inv;
+        const float f2_x0 = fmaf(bdo_x0, pi_x0, boe_x0), f2_xt = fmaf(bdo_xt, pi_xt, boe_xt);
+        const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
+        const float b_x0 = boe_x0 + bdo_x0, b_xt = fmaf(same, bdo_xt, boe_xt);
+        const float a_x0 = fmaf(same, da, a_o);
+        const float Zt = fmaf(a_o, sum_boe + bdo_x0, da * b_xt);
+        const float Zm = fmaf(a_o, Sf, da * f2_xt);
+        const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
+        // kl = sum_j q_j log2(q_j / p_j), q_j / p_j = (b_j / f2_j) (Zm / Zt): every log is of a ratio that
+        // is close to one wherever q_j is large, so nothing cancels
+        const float zr = Zm * izt;
+        const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
+        // ---- round 4: kl sum, <pi, g pi>
+        float h[L::V], S1 = 0, D = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
-          gpi[v] = fmaf(gf2[v], P.bd[v] - P.bo[v], R);
-          dot += pi[v] * gpi[v];
+          S1 = fmaf(boe[v], fast_log2(pr[v] * zr), S1);       // masked slots: boe = 1 but pr * zr != 1
+          if constexpr (!L::VEC) S1 = (L::cls(g, v) < K) ? S1 : S1 - fast_log2(pr[v] * zr);
+          if constexpr (GRAD) {
+            h[v] = fmaf(-A2, pr[v], A1) * bdo[v];
+            D = fmaf(pi[v], h[v], D);
+          }
         }
-        dot = group_sum<L::G>(dot);
+        S1 = group_sum<L::G>(S1);
+        if constexpr (GRAD) D = group_sum<L::G>(D);
+        float kls = a_o * S1;
+        kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
+        kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
+        kls = fmaf((1.0f - same) * da * boe_xt, fast_log2(boe_xt * rf_xt * zr), kls);
+        acc_vb = fmaf(tok, kls * izt, acc_vb);
+        if constexpr (GRAD) {
+          const float d_x0 = -A2 * bdo_x0 * rf_x0;                       // added to gf2 at class x0
+          const float d_xt = w_vb * da * (izm - b_xt * rf_xt * izt);     // added to gf2 at class x_t
+          const float bo_x0 = boe_x0 - eps, bo_xt = boe_xt - eps;
+          const float R = fmaf(A1, sum_bo, fmaf(-A2, Rp, fmaf(d_x0, bo_x0, d_xt * bo_xt)));
+          const float p0 = pi_x0 * d_x0 * bdo_x0, pt = pi_xt * d_xt * bdo_xt;   // pi_j * (extra g pi_j) at x0, x_t
+          const float dot = R + D + p0 + pt;
+          const float C = R - dot + w_ce;
+          // additive patches at the two special classes (one class when x0 == x_t)
+          const float add0 = p0 - w_ce + same * pt, addt = (1.0f - same) * pt;
 #pragma unroll
-        for (int v = 0; v < L::V; ++v)
-          gz[v] = pi[v] * (gpi[v] - dot) + w_ce * (pi[v] - ((L::cls(g, v) == x0) ? 1.0f : 0.0f));
+          for (int v = 0; v < L::V; ++v) {
+            const float patch = (d0 == v * CS) ? add0 : ((dt == v * CS) ? addt : 0.0f);
+            gz[v] = fmaf(pi[v], h[v] + C, patch);
+          }
+        }
+      }
+      if constexpr (GRAD) {
+        store_slots_off<L>(drow, pos * row_bytes, g, K, gz);
+        if (!L::VEC && ld > K) zero_tail<L>(reinterpret_cast<float*>(drow + (size_t)pos * row_bytes), g, K, ld);
       }
     }
-    if constexpr (GRAD) {
-      store_slots<L>(dlogits + n * ld, g, K, gz);
-      if (!L::VEC && ld > K) zero_tail<L>(dlogits + n * ld, g, K, ld);
-    }
-    if (g == 0) { acc_vb += vb; acc_ce += ce; }
   }
-  // workgroup partial sums (fixed order: lanes by butterfly, waves in index order)
+  // workgroup sums (fixed order: lanes by butterfly, waves in index order)
   acc_vb = wave_sum(acc_vb);
   acc_ce = wave_sum(acc_ce);
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float svb = 0, sce = 0;
-    for (int w = 0; w < BLOCK / 64; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
-    part[((size_t)b * a.chunks + chunk) * 2 + 0] = svb;
-    part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
+    for (int w = 0; w < nw; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
+    if (a.chunks == 1) {
+      write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
+    } else {
+      out.part[((size_t)b * a.chunks + chunk) * 2 + 0] = svb;
+      out.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
+    }
   }
 }
 
-__global__ void k_loss_finalize(const float* __restrict__ part, int B, int chunks, long npos, int loss_type,
-                                float hybrid_coeff, float* __restrict__ vb, float* __restrict__ ce,
-                                float* __restrict__ loss) {
+// Sums of the per-workgroup partials in chunk order; `unit` converts them to
+// bits (1 for partials already in bits, 1/ln2 for partials in nats).
+__global__ void k_loss_finalize(LossOut out, int B, int chunks, long npos, int loss_type, float hybrid_coeff,
+                                float unit) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float svb = 0, sce = 0;
   for (int c = 0; c < chunks; ++c) {
-    svb += part[((size_t)b * chunks + c) * 2 + 0];
-    sce += part[((size_t)b * chunks + c) * 2 + 1];
+    svb += out.part[((size_t)b * chunks + c) * 2 + 0];
+    sce += out.part[((size_t)b * chunks + c) * 2 + 1];
   }
-  const float v = svb / (float)npos / LN2, c_ = sce / (float)npos / LN2;
-  if (vb) vb[b] = v;
-  if (ce) ce[b] = c_;
-  if (loss) loss[b] = loss_type == D3PM_LOSS_KL ? v : (loss_type == D3PM_LOSS_CE ? c_ : v + hybrid_coeff * c_);
+  write_losses(out, b, svb * unit, sce * unit, npos, loss_type, hybrid_coeff);
 }
 
 // ------------------------------------------------------------------ p_sample
@@ -563,29 +704,53 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
   }
   if (B == 0) return D3PM_OK;
   D3PM_CHECK_ARG(npos > 0, "empty sample: mean over zero positions");
+  D3PM_CHECK_ARG(npos * ld < 0x3fffffffL, "one batch element spans %ld logits: more than 2^30", npos * ld);
   D3PM_CHECK_ARG(logits && x0 && x_t && t, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (!tb->structured)
     return dense_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type, hybrid_coeff,
                              grad_scale, grad_out, vb, ce, loss, dlogits, workspace, workspace_bytes, s);
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits));
-  return dispatch_layout(tb->K, vec, [&](auto lay) {
+  return dispatch_layout_wide(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, L::G);
-    const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
-    float* part = (float*)workspace;
-    const dim3 grid(B * a.chunks), block(BLOCK);
+    // A batch that fills the chip on its own gets one workgroup per batch element
+    // (sized so each lane group makes one PIPE-deep trip) and writes its losses
+    // directly; small batches are split over chunks and summed by k_loss_finalize.
+    int block = BLOCK;
+    if (B >= 192) {
+      static const int tpg = getenv("D3PM_TOKENS_PER_GROUP") ? atoi(getenv("D3PM_TOKENS_PER_GROUP")) : 8;
+      long want = ((npos + tpg - 1) / tpg) * L::G;       // lane groups make ~tpg trips each
+      want = ((want + 63) / 64) * 64;
+      const long cap = loss_max_threads<L>();
+      block = (int)(want < 64 ? 64 : (want > cap ? cap : want));
+      a.chunks = 1;
+      a.chunk_pos = npos;
+    } else {
+      const TokenGrid tg = token_grid(B, npos, pipe_depth<L>() * (BLOCK / L::G), 1024);
+      a.chunks = tg.chunks;
+      a.chunk_pos = tg.chunk_pos;
+    }
+    LossOut o{vb, ce, loss, nullptr};
+    if (a.chunks > 1) {
+      const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes,
+                     need);
+      o.part = (float*)workspace;
+    }
+    const dim3 grid(B * a.chunks), blk(block);
     if (dlogits)
-      hipLaunchKernelGGL((k_hybrid_loss<L, true>), grid, block, 0, s, a, logits, ld, loss_type, hybrid_coeff, grad_scale,
-                         grad_out, part, dlogits);
+      hipLaunchKernelGGL((k_hybrid_loss<L, true>), grid, blk, 0, s, a, logits, ld, loss_type, hybrid_coeff, grad_scale,
+                         grad_out, o, dlogits);
     else
-      hipLaunchKernelGGL((k_hybrid_loss<L, false>), grid, block, 0, s, a, logits, ld, loss_type, hybrid_coeff, grad_scale,
-                         grad_out, part, dlogits);
+      hipLaunchKernelGGL((k_hybrid_loss<L, false>), grid, blk, 0, s, a, logits, ld, loss_type, hybrid_coeff, grad_scale,
+                         grad_out, o, dlogits);
     D3PM_LAUNCH_CHECK("k_hybrid_loss");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, loss_type,
-                       hybrid_coeff, vb, ce, loss);
-    D3PM_LAUNCH_CHECK("k_loss_finalize");
+    if (a.chunks > 1) {
+      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, o, B, a.chunks, npos, loss_type,
+                         hybrid_coeff, 1.0f);
+      D3PM_LAUNCH_CHECK("k_loss_finalize");
+    }
     return D3PM_OK;
   });
 }
@@ -657,8 +822,8 @@ extern "C" int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_prior");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, D3PM_LOSS_KL,
-                       0.0f, out, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{out, nullptr, nullptr, part}, B,
+                       a.chunks, npos, D3PM_LOSS_KL, 0.0f, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;
   });

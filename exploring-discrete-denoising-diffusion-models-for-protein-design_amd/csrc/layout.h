@@ -3,6 +3,8 @@
 #pragma once
 #include "d3pm_device.h"
 
+#include <cstdlib>
+
 namespace d3pm {
 
 template <int G_, int V_, bool VEC_>
@@ -11,15 +13,19 @@ struct Layout {
   static constexpr int V = V_;        // class slots per lane
   static constexpr bool VEC = VEC_;   // slots contiguous (one 16-byte access)
   static constexpr int TOKENS_PER_WAVE = 64 / G_;
-  __device__ static __forceinline__ int cls(int g, int v) { return VEC_ ? 4 * g + v : g + G_ * v; }
+  static_assert(!VEC_ || V_ % 4 == 0, "vector layouts hold whole 16-byte pieces");
+  __device__ static __forceinline__ int cls(int g, int v) { return VEC_ ? V_ * g + v : g + G_ * v; }
 };
 
 // Load one token's slots of a float row; masked slots read `fill`.
 template <class L>
 __device__ __forceinline__ void load_slots(const float* __restrict__ row, int g, int K, float fill, float (&z)[L::V]) {
   if constexpr (L::VEC) {
-    const float4 q = *reinterpret_cast<const float4*>(row + 4 * g);
-    z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+#pragma unroll
+    for (int h = 0; h < L::V / 4; ++h) {
+      const float4 q = *reinterpret_cast<const float4*>(row + L::V * g + 4 * h);
+      z[4 * h + 0] = q.x; z[4 * h + 1] = q.y; z[4 * h + 2] = q.z; z[4 * h + 3] = q.w;
+    }
   } else {
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
@@ -37,10 +43,50 @@ __device__ __forceinline__ void load_slots(const double* __restrict__ row, int g
   }
 }
 
+// The same through a wave-uniform base and a 32-bit byte offset of the row, so
+// the access is one scalar-base + vector-offset instruction with no 64-bit
+// address arithmetic per lane.
+template <class L>
+__device__ __forceinline__ void load_slots_off(const char* __restrict__ base, unsigned row_off, int g, int K,
+                                               float fill, float (&z)[L::V]) {
+  if constexpr (L::VEC) {
+#pragma unroll
+    for (int h = 0; h < L::V / 4; ++h) {
+      const float4 q = *reinterpret_cast<const float4*>(base + (row_off + 4u * L::V * (unsigned)g + 16u * h));
+      z[4 * h + 0] = q.x; z[4 * h + 1] = q.y; z[4 * h + 2] = q.z; z[4 * h + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      z[v] = c < K ? *reinterpret_cast<const float*>(base + (row_off + 4u * (unsigned)c)) : fill;
+    }
+  }
+}
+template <class L>
+__device__ __forceinline__ void store_slots_off(char* __restrict__ base, unsigned row_off, int g, int K,
+                                                const float (&z)[L::V]) {
+  if constexpr (L::VEC) {
+#pragma unroll
+    for (int h = 0; h < L::V / 4; ++h)
+      *reinterpret_cast<float4*>(base + (row_off + 4u * L::V * (unsigned)g + 16u * h)) =
+          make_float4(z[4 * h + 0], z[4 * h + 1], z[4 * h + 2], z[4 * h + 3]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      if (c < K) *reinterpret_cast<float*>(base + (row_off + 4u * (unsigned)c)) = z[v];
+    }
+  }
+}
+
 template <class L>
 __device__ __forceinline__ void store_slots(float* __restrict__ row, int g, int K, const float (&z)[L::V]) {
   if constexpr (L::VEC) {
-    *reinterpret_cast<float4*>(row + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+#pragma unroll
+    for (int h = 0; h < L::V / 4; ++h)
+      *reinterpret_cast<float4*>(row + L::V * g + 4 * h) =
+          make_float4(z[4 * h + 0], z[4 * h + 1], z[4 * h + 2], z[4 * h + 3]);
   } else {
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
@@ -81,6 +127,25 @@ int dispatch_layout(int K, bool vec_ok, F&& f) {
   if (K <= 256) return f(Layout<64, 4, false>{});
   set_error("K = %d is not supported (2 <= K <= 256)", K);
   return D3PM_EUNSUPPORTED;
+}
+
+// As dispatch_layout, but with 8 classes per lane where K allows: fewer lanes
+// per token means fewer cross-lane reduction steps and less per-token work
+// repeated in every lane.  For kernels whose per-class register footprint is
+// small enough to afford it.
+template <class F>
+int dispatch_layout_wide(int K, bool vec_ok, F&& f) {
+  static const int lanes = getenv("D3PM_WIDE") ? atoi(getenv("D3PM_WIDE")) : 1;
+  if (vec_ok && lanes) {
+    switch (K) {
+      case 32: return f(Layout<4, 8, true>{});
+      case 64: return f(Layout<8, 8, true>{});
+      case 128: return f(Layout<16, 8, true>{});
+      case 256: return f(Layout<32, 8, true>{});
+      default: break;
+    }
+  }
+  return dispatch_layout(K, vec_ok, f);
 }
 
 // Grid for kernels that walk [B, npos] tokens with one batch element per
