@@ -31,6 +31,21 @@ B, L, K, T = 256, 512, 32, 500
 LAMBDA = 0.001
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 BYTES_PER_TOKEN = 8 * K + 16   # logits in + dlogits out (float32) + x0 + x_t (int64)
+# HBM bytes per launch of the fused loss kernel from the PMC passes kept under profiles/
+# (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), or None when no profile is committed.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
+
+
+def measured_traffic():
+    try:
+        prof = json.load(open(TRAFFIC_FILE))
+        for name, ctr in prof.items():
+            if "k_hybrid_loss" in name and "true>(" in name[name.index("k_hybrid_loss"):] \
+                    and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                return (2 * ctr["FETCH_SIZE"]["mean_per_launch"] + ctr["WRITE_SIZE"]["mean_per_launch"]) * 1024
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(budget_s: float = 12.0):
@@ -72,6 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
     args = ap.parse_args()
 
@@ -103,20 +119,20 @@ def main():
     logits = torch.randn(B, L, 1, 1, K, device=dev, requires_grad=True)
     model_fn = lambda x, tt: logits
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
 
-    def step(i=None):
-        t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
-        x_t = d.q_sample(x0, t)                               # Philox noise on device
-        if i is not None:
-            ev0[i].record()
-        losses = d._fused(logits, x0, x_t, t, "hybrid")      # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
-        if i is not None:
-            ev1[i].record()
-        logits.grad = None
-        losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
-        return losses
+    if args.no_graph:
+        def step():
+            t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+            x_t = d.q_sample(x0, t)                               # Philox noise on device
+            losses = d._fused(logits, x0, x_t, t, "hybrid")      # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
+            logits.grad = None
+            losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
+    else:
+        # the same calls captured into one HIP graph (timestep draw, q_sample with a device-side
+        # Philox counter, fused loss, .mean(), backward) and replayed
+        graphed = d3pm_amd.graphs.GraphedTrainingLosses(d, model_fn, x0, seed=1234 + rank, params=[logits])
+        step = graphed.replay
 
     for _ in range(args.warmup):
         step()
@@ -126,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -136,8 +152,35 @@ def main():
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
     tokens = B * L * args.steps * world
+
+    # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the
+    # stream, HIP events at both ends; rocprofv3 --kernel-trace of this command reports the same
+    # kernel's average duration (profiles/).
+    tb = d.tables()
+    t_s = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+    xt_s = d.q_sample(x0, t_s)
+    lg_s, dl_s = logits.detach(), torch.empty_like(logits)
+    loss_s = torch.empty(B, device=dev)
+    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+    ws = torch.empty(max(wsb // 4, 1), device=dev)
+    sp = stream_ptr()
+
+    def fused_only():
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_s), K, ptr(x0), 8, ptr(xt_s), 8, ptr(t_s), 4, B, L,
+                                   LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_s), ptr(ws),
+                                   wsb, sp))
+
+    for _ in range(10):
+        fused_only()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        fused_only()
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / args.steps
 
     # ---- secondary: reverse sampling, path only (frozen logits), 10k BLAT-length sequences sharded
     n_local = (10000 + world - 1) // world
@@ -173,10 +216,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic protein D3PM B={B} L={L} K={K} T={T} {args.kind} Q, per GPU: q_sample "
                                    "(Philox) + fused posterior/hybrid-loss fwd+bwd to dlogits, denoiser excluded",
-                       "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective"},
+                       "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective",
+                       "launch": "eager" if args.no_graph else "hip-graph replay"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_hybrid_loss (+ k_loss_finalize), HIP events around d3pm_hybrid_loss",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN},
             "reverse_sample": {"value": min(done, n_local) * world / rev_el, "unit": "seqs/s",
                                "what": "full T=500 (499 steps) reverse sampling, L=263, K=22, 10000 sequences sharded "

@@ -9,6 +9,7 @@ without that library raises.
 """
 from . import _lib  # noqa: F401  (loads libd3pm_hip.so or raises)
 from . import tables  # noqa: F401
+from . import graphs  # noqa: F401
 from . import d3pm  # noqa: F401
 from . import protein_generation  # noqa: F401
 from .d3pm import DiscreteDiffusion, generate_betas  # noqa: F401

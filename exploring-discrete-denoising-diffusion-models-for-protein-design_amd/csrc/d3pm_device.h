@@ -158,4 +158,12 @@ __device__ __forceinline__ float gumbel_from_uniform(float u) {
   return -logf(-logf(u));
 }
 
+// The same transform on hardware log2 (v_log_f32), for noise drawn on the device,
+// where no bit pattern has to match a host computation.
+__device__ __forceinline__ float gumbel_from_uniform_fast(float u) {
+  u = fmaxf(u, 1.17549435e-38f);
+  const float ln2 = 0.693147180559945309417f;
+  return -ln2 * __builtin_amdgcn_logf(-ln2 * __builtin_amdgcn_logf(u));
+}
+
 }  // namespace d3pm

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(BLOCK) void k_dense_q_probs(ImgArgs a, float* __res
 
 template <class L, int NOISE>
 __global__ __launch_bounds__(BLOCK) void k_dense_q_sample(ImgArgs a, const float* __restrict__ noise, uint64_t seed,
-                                                          uint64_t offset, int64_t* __restrict__ out) {
+                                                          uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                          int64_t* __restrict__ out) {
+  if (NOISE == D3PM_NOISE_PHILOX && offset_dev) offset += *offset_dev;
   const int K = a.tb.K;
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
@@ -170,7 +172,7 @@ struct DenseExtra {
   // posterior logits out / probs out
   float* out; float* probs;
   // sampling
-  const float* noise; uint64_t seed, offset; int64_t* sample;
+  const float* noise; uint64_t seed, offset; const uint64_t* offset_dev; int64_t* sample;
 };
 
 template <class L, int MODE, bool GRAD, int NOISE>
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
     w_ce = (e.loss_type == D3PM_LOSS_KL) ? 0.0f : (e.loss_type == D3PM_LOSS_CE ? cnorm : e.hybrid_coeff * cnorm);
   }
   float acc_vb = 0, acc_ce = 0;
+  if (MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX && e.offset_dev) e.offset += *e.offset_dev;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += C::TM) {
     // ---- phase 1: softmax of the tile's logits into LDS, CE term
@@ -408,19 +411,22 @@ static int dense_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_byte
 }
 
 static int dense_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes, int B,
-                          long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset, int64_t* x_t,
-                          hipStream_t s) {
+                          long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
+                          const uint64_t* offset_dev, int64_t* x_t, hipStream_t s) {
   const bool vec = aligned16(tb->qbar) && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise));
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);
     const dim3 grid(B * a.chunks), block(BLOCK);
     if (noise_kind == D3PM_NOISE_UNIFORM)
-      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     else if (noise_kind == D3PM_NOISE_GUMBEL)
-      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     else
-      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     D3PM_LAUNCH_CHECK("k_dense_q_sample");
     return D3PM_OK;
   });
@@ -487,14 +493,15 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
 
 static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x_t, int xt_bytes,
                           const void* t, int t_bytes, int B, long npos, const float* noise, int noise_kind,
-                          uint64_t seed, uint64_t offset, int64_t* sample, float* probs, hipStream_t s) {
+                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* sample, float* probs,
+                          hipStream_t s) {
   const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
                    (!probs || aligned16(probs)) && aligned16(tb->qbar) && aligned16(tb->qoneT);
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_dense_args<L>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
     DenseExtra e{};
-    e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.sample = sample; e.probs = probs;
+    e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.offset_dev = offset_dev; e.sample = sample; e.probs = probs;
     const dim3 grid(B * a.chunks), block(BLOCK);
     const size_t sh = dense_lds_bytes<L>(tb->K, false);
     if (noise_kind == D3PM_NOISE_UNIFORM)

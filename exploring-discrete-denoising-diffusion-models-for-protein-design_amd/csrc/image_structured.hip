@@ -61,7 +61,9 @@ __global__ __launch_bounds__(BLOCK) void k_q_probs(ImgArgs a, float* __restrict_
 // ------------------------------------------------------------------ q_sample
 template <class L, int NOISE>
 __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __restrict__ noise, uint64_t seed,
-                                                    uint64_t offset, int64_t* __restrict__ out) {
+                                                    uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                    int64_t* __restrict__ out) {
+  if (NOISE == D3PM_NOISE_PHILOX && offset_dev) offset += *offset_dev;
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
       const int c = L::cls(g, v);
-      const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]);
+      const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v]
+                        : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v]));
       const float val = ((c == x0) ? ld_[v] : lo_[v]) + gum;
       const bool ok = c < K;
       // NaN-free inputs: strict > keeps the first maximal class of this lane
@@ -257,6 +260,25 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
   const unsigned pbeg = (unsigned)(chunk * a.chunk_pos) + slot;
   const unsigned row_bytes = (unsigned)ld * 4u;
 
+  // Start-up order: the timestep (a scalar load), then the few digest rows that
+  // depend on it, then the first rows of logits; vector loads return in issue
+  // order, so the digests must not queue behind the row burst.
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
+  float bdo[L::V], boe[L::V], bo[L::V];
+  float sum_boe = 0, sum_bo = 0;
+  float f_ad = 0, f_ao = 0, f_d = 0, f_o = 0;
+  if (need_post) {
+    load_digest<L>(a.tb.qbar_digest, t - 1, 0, K, g, bdo);     // diag for now
+    load_digest<L>(a.tb.qbar_digest, t - 1, 1, K, g, bo);
+    if (threadIdx.x < K) {                   // K <= blockDim.x (checked by the host)
+      f_ad = dg(a.tb.qone_digest, t, 0, K)[threadIdx.x];
+      f_ao = dg(a.tb.qone_digest, t, 1, K)[threadIdx.x];
+      f_d = dg(a.tb.qbar_digest, t - 1, 0, K)[threadIdx.x];
+      f_o = dg(a.tb.qbar_digest, t - 1, 1, K)[threadIdx.x];
+    }
+  }
+
   float zz[PIPE][L::V];
   int x0s[PIPE], xts[PIPE];
   auto issue_load = [&](int u, unsigned pos) {
@@ -277,37 +299,29 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
     sp0[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)x0s[u]));
     spt[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)xts[u]));
   };
-  if (pbeg < p1) issue_special(0, pbeg);
 
-  const int t = load_tok(a.t, b, a.t_bytes);
-  const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
   // per-class constants of Qbar_{t-1} for this lane's slots, and their sums over all classes
-  float bdo[L::V], boe[L::V], bo[L::V];
-  float sum_boe = 0, sum_bo = 0;
   if (need_post) {
-    float bd[L::V];
-    load_digest<L>(a.tb.qbar_digest, t - 1, 0, K, g, bd);
-    load_digest<L>(a.tb.qbar_digest, t - 1, 1, K, g, bo);
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
       const bool ok = L::VEC || L::cls(g, v) < K;
-      bdo[v] = ok ? bd[v] - bo[v] : 0.0f;
-      boe[v] = ok ? bo[v] + eps : 1.0f;        // masked slots: f2 = 1, log 1 = 0
+      bdo[v] = ok ? bdo[v] - bo[v] : 0.0f;
+      boe[v] = ok ? bo[v] + eps : 1.0f;        // masked slots: f2 = 1
       bo[v] = ok ? bo[v] : 0.0f;
       sum_boe += ok ? boe[v] : 0.0f;
       sum_bo += bo[v];
     }
     sum_boe = group_sum<L::G>(sum_boe);
     sum_bo = group_sum<L::G>(sum_bo);
-    for (int j = threadIdx.x; j < K; j += blockDim.x) {
-      s_ad[j] = dg(a.tb.qone_digest, t, 0, K)[j] + eps;
-      s_ao[j] = dg(a.tb.qone_digest, t, 1, K)[j] + eps;
-      const float d = dg(a.tb.qbar_digest, t - 1, 0, K)[j], o = dg(a.tb.qbar_digest, t - 1, 1, K)[j];
-      s_bdo[j] = d - o;
-      s_boe[j] = o + eps;
+    if (threadIdx.x < K) {
+      s_ad[threadIdx.x] = f_ad + eps;
+      s_ao[threadIdx.x] = f_ao + eps;
+      s_bdo[threadIdx.x] = f_d - f_o;
+      s_boe[threadIdx.x] = f_o + eps;
     }
     __syncthreads();
   }
+  if (pbeg < p1) issue_special(0, pbeg);
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
   // weights of d(vb)/dz and d(ce)/dz in the requested loss
@@ -461,7 +475,9 @@ __global__ void k_loss_finalize(LossOut out, int B, int chunks, long npos, int l
 template <class L, int NOISE>
 __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __restrict__ logits, long ld,
                                                     const float* __restrict__ noise, uint64_t seed, uint64_t offset,
+                                                    const uint64_t* __restrict__ offset_dev,
                                                     int64_t* __restrict__ sample, float* __restrict__ probs) {
+  if (NOISE == D3PM_NOISE_PHILOX && offset_dev) offset += *offset_dev;
   const int K = a.tb.K;
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
@@ -501,7 +517,8 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
       for (int v = 0; v < L::V; ++v) {
         const int c = L::cls(g, v);
         const float f2 = fmaf(P.bd[v] - P.bo[v], pi[v], P.bo[v]);
-        const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]);
+        const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v]
+                          : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v]));
         const float val = (((c == xt) ? l1d : l1o) + logf(f2 + eps)) + gum;
         if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
       }
@@ -628,7 +645,7 @@ extern "C" int d3pm_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_b
 
 extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes, int B,
                              long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
-                             int64_t* x_t, void* stream) {
+                             const uint64_t* offset_dev, int64_t* x_t, void* stream) {
   if (int rc = check_common(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(bytes_ok(tok_bytes) && bytes_ok(t_bytes), "token/timestep width must be 4 or 8 bytes");
   D3PM_CHECK_ARG(noise_kind == D3PM_NOISE_UNIFORM || noise_kind == D3PM_NOISE_GUMBEL || noise_kind == D3PM_NOISE_PHILOX,
@@ -638,17 +655,20 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
   D3PM_CHECK_ARG(noise_kind == D3PM_NOISE_PHILOX || noise, "noise tensor is null");
   hipStream_t s = (hipStream_t)stream;
   if (!tb->structured)
-    return dense_q_sample(tb, x0, tok_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, x_t, s);
+    return dense_q_sample(tb, x0, tok_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, offset_dev, x_t, s);
   return dispatch_layout(tb->K, noise_kind == D3PM_NOISE_PHILOX || aligned16(noise), [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);
     const dim3 grid(B * a.chunks), block(BLOCK);
     if (noise_kind == D3PM_NOISE_UNIFORM)
-      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     else if (noise_kind == D3PM_NOISE_GUMBEL)
-      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     else
-      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, noise, seed, offset, x_t);
+      hipLaunchKernelGGL((k_q_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, noise, seed, offset, offset_dev,
+                         x_t);
     D3PM_LAUNCH_CHECK("k_q_sample");
     return D3PM_OK;
   });
@@ -723,6 +743,7 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
       long want = ((npos + tpg - 1) / tpg) * L::G;       // lane groups make ~tpg trips each
       want = ((want + 63) / 64) * 64;
       const long cap = loss_max_threads<L>();
+      if (want < tb->K) want = ((tb->K + 63) / 64) * 64;      // one thread per class stages the digests
       block = (int)(want < 64 ? 64 : (want > cap ? cap : want));
       a.chunks = 1;
       a.chunk_pos = npos;
@@ -772,7 +793,8 @@ extern "C" int d3pm_scale_rows(float* g, const float* upstream, float baked, int
 
 extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x_t, int xt_bytes,
                              const void* t, int t_bytes, int B, long npos, const float* noise, int noise_kind,
-                             uint64_t seed, uint64_t offset, int64_t* sample, float* probs, void* stream) {
+                             uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* sample, float* probs,
+                             void* stream) {
   if (int rc = check_common(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(bytes_ok(xt_bytes) && bytes_ok(t_bytes), "token/timestep width must be 4 or 8 bytes");
   D3PM_CHECK_ARG(ld >= tb->K, "row stride %ld smaller than K=%d", ld, tb->K);
@@ -783,8 +805,8 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
   D3PM_CHECK_ARG(noise_kind == D3PM_NOISE_PHILOX || noise, "noise tensor is null");
   hipStream_t s = (hipStream_t)stream;
   if (!tb->structured)
-    return dense_p_sample(tb, logits, ld, x_t, xt_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, sample,
-                          probs, s);
+    return dense_p_sample(tb, logits, ld, x_t, xt_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, offset_dev,
+                          sample, probs, s);
   const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
                    (!probs || aligned16(probs));
   return dispatch_layout(tb->K, vec, [&](auto lay) {
@@ -793,13 +815,13 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
     const dim3 grid(B * a.chunks), block(BLOCK);
     if (noise_kind == D3PM_NOISE_UNIFORM)
       hipLaunchKernelGGL((k_p_sample<L, D3PM_NOISE_UNIFORM>), grid, block, 0, s, a, logits, ld, noise, seed, offset,
-                         sample, probs);
+                         offset_dev, sample, probs);
     else if (noise_kind == D3PM_NOISE_GUMBEL)
       hipLaunchKernelGGL((k_p_sample<L, D3PM_NOISE_GUMBEL>), grid, block, 0, s, a, logits, ld, noise, seed, offset,
-                         sample, probs);
+                         offset_dev, sample, probs);
     else
       hipLaunchKernelGGL((k_p_sample<L, D3PM_NOISE_PHILOX>), grid, block, 0, s, a, logits, ld, noise, seed, offset,
-                         sample, probs);
+                         offset_dev, sample, probs);
     D3PM_LAUNCH_CHECK("k_p_sample");
     return D3PM_OK;
   });

@@ -187,17 +187,25 @@ class DiscreteDiffusion:
                                    stream_ptr()))
         return out
 
-    def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform"):
-        """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64."""
+    def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform", rng=None):
+        """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64.
+        ``rng=(seed, counter)`` with ``counter`` a one-element int64 device
+        tensor selects the Philox stream explicitly (for HIP-graph capture,
+        where the caller advances ``counter`` inside the graph)."""
         x = _as_tokens(x_start)
         _lib.require_device(x)
         tb = self.tables()
         B, npos = self._dims(x)
         t = _as_tokens(t)
         seed = off = 0
+        off_dev = None
         if noise is None:
             kind = _lib.NOISE_PHILOX
-            seed, off = _philox_ticket(x.device)
+            if rng is not None:
+                seed, off_dev = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, rng[1]
+                assert off_dev.dtype == torch.int64 and off_dev.is_cuda
+            else:
+                seed, off = _philox_ticket(x.device)
         else:
             assert noise.shape == x.shape + (tb.K,), noise.shape
             kind = _lib.NOISE[noise_kind]
@@ -205,7 +213,7 @@ class DiscreteDiffusion:
         out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
         with torch.cuda.device(x.device):
             check(lib.d3pm_q_sample(tb.desc(), ptr(x), tok_bytes(x), ptr(t), tok_bytes(t), B, npos, ptr(noise), kind,
-                                    seed, off, ptr(out), stream_ptr()))
+                                    seed, off, ptr(off_dev), ptr(out), stream_ptr()))
         return out
 
     # ------------------------------------------------------------------ posterior
@@ -290,7 +298,7 @@ class DiscreteDiffusion:
         probs = torch.empty_like(lg) if want_probs else None
         with torch.cuda.device(xt.device):
             check(lib.d3pm_p_sample(tb.desc(), ptr(lg), K, ptr(xt), tok_bytes(xt), ptr(t), tok_bytes(t), B, npos,
-                                    ptr(noise), kind, seed, off, ptr(sample), ptr(probs), stream_ptr()))
+                                    ptr(noise), kind, seed, off, None, ptr(sample), ptr(probs), stream_ptr()))
         return sample, probs
 
     @torch.no_grad()
@@ -368,15 +376,15 @@ class DiscreteDiffusion:
         assert ce.shape == (x_start.shape[0],)
         return ce
 
-    def training_losses(self, model_fn, *, x_start, t=None, noise=None, noise_kind: str = "uniform"):
+    def training_losses(self, model_fn, *, x_start, t=None, noise=None, noise_kind: str = "uniform", rng=None):
         """Per-example training loss (:545-582).  `t` and `noise` default to
-        on-device draws (uniform t in [0, T), Philox noise)."""
+        on-device draws (uniform t in [0, T), Philox noise); `rng` as in q_sample."""
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         B = x_start.shape[0]
         if t is None:
             t = torch.randint(0, self.num_timesteps, (B,), dtype=torch.int32, device=self.device)
-        x_t = self.q_sample(x_start=x_start, t=t, noise=noise, noise_kind=noise_kind)
+        x_t = self.q_sample(x_start=x_start, t=t, noise=noise, noise_kind=noise_kind, rng=rng)
         pred = self._denoiser_logits(model_fn, x_t, t)
         if self.model_prediction != "x_start":
             raise NotImplementedError(self.model_prediction)

@@ -1,0 +1,59 @@
+"""HIP-graph capture of the loss step.
+
+One training step of the image-style process is a handful of short kernels
+(timestep draw, forward corruption, fused loss, the caller's reduction and its
+backward); launched eagerly from Python the step is bound by host launch
+overhead, not by the GPU.  ``GraphedTrainingLosses`` captures the whole step,
+including ``loss.backward()``, into one HIP graph and replays it.  Fresh noise
+on every replay comes from a device-side Philox counter that the graph itself
+advances.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedTrainingLosses:
+    """``DiscreteDiffusion.training_losses(model_fn, x_start=...)`` followed by
+    ``.mean().backward()``, captured once and replayed.
+
+    ``x_start`` is a static input buffer (copy new data into it between
+    replays); ``model_fn`` must be capturable (static shapes, no host syncs);
+    gradients land in the ``.grad`` of the tensors ``model_fn`` depends on.
+    ``params`` lists those leaf tensors: their ``.grad`` is cleared before the
+    capture so that the captured backward writes gradients instead of
+    accumulating into the warm-up's (one elementwise pass less per step); read
+    ``p.grad`` after ``replay()``.
+    """
+
+    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0, warmup: int = 3, params=()):
+        self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
+        self.seed = int(seed)
+        dev = x_start.device
+        # parameters usually predate the capture stream; the mismatch torch warns about is intended here
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        diffusion.tables()                                   # builds digests now: set-up syncs are not capturable
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body().backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for p in params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+            self.loss.backward()
+
+    def _body(self):
+        self.counter.add_(4)
+        losses = self.diffusion.training_losses(self.model_fn, x_start=self.x_start, rng=(self.seed, self.counter))
+        self.losses = losses
+        return losses.mean()
+
+    def replay(self) -> torch.Tensor:
+        """One step; returns the (static) scalar loss tensor."""
+        self.graph.replay()
+        return self.loss

@@ -126,10 +126,12 @@ int d3pm_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const
                  int B, long npos, float* out, void* stream);
 
 /* q_sample (:266-285): x_t = argmax_j(log(q_probs + eps) + gumbel), first
- * maximal index; x_t int64.  noise_kind UNIFORM / GUMBEL / PHILOX. */
+ * maximal index; x_t int64.  noise_kind UNIFORM / GUMBEL / PHILOX.  For PHILOX
+ * the stream is (seed, offset + *offset_dev); offset_dev (device, may be NULL)
+ * lets a captured HIP graph draw fresh noise on every replay. */
 int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes,
                   int B, long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
-                  int64_t* x_t, void* stream);
+                  const uint64_t* offset_dev, int64_t* x_t, void* stream);
 
 /* q_posterior_logits (:312-336).  x_start_is_logits == 0: x_start is a token
  * array; != 0: float32 logits [B,npos,ld].  out float32 [B,npos,K].  With
@@ -164,10 +166,12 @@ int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld,
 int d3pm_scale_rows(float* g, const float* upstream, float baked, int B, long row_elems, void* stream);
 
 /* p_sample (:384-403): sample = argmax_j(p_logits + [t!=0]*gumbel) int64;
- * probs (may be NULL) = softmax(logits) float32 [B,npos,K]. */
+ * probs (may be NULL) = softmax(logits) float32 [B,npos,K].  offset_dev as in
+ * d3pm_q_sample. */
 int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x_t, int xt_bytes,
                   const void* t, int t_bytes, int B, long npos, const float* noise, int noise_kind,
-                  uint64_t seed, uint64_t offset, int64_t* sample, float* probs, void* stream);
+                  uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* sample, float* probs,
+                  void* stream);
 
 /* prior_bpd (:492-524): KL(q(x_{T-1}|x0) || stationary)/ln2 averaged over
  * positions; stationary is uniform, or one-hot at K/2 when absorbing != 0.

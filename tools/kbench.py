@@ -62,12 +62,12 @@ def main():
                                    0.001, 1.0 / B, None, None, None, ptr(loss), None, ptr(ws), wsb, s))
 
     def f_qs():
-        check(lib.d3pm_q_sample(tb.desc(), ptr(x0), 8, ptr(t), 4, B, L, None, NOISE_PHILOX, 1, 0, ptr(x_t), s))
+        check(lib.d3pm_q_sample(tb.desc(), ptr(x0), 8, ptr(t), 4, B, L, None, NOISE_PHILOX, 1, 0, None, ptr(x_t), s))
 
     samp = torch.empty_like(x0)
 
     def f_ps():
-        check(lib.d3pm_p_sample(tb.desc(), ptr(logits), K, ptr(x_t), 8, ptr(t), 4, B, L, None, NOISE_PHILOX, 1, 0,
+        check(lib.d3pm_p_sample(tb.desc(), ptr(logits), K, ptr(x_t), 8, ptr(t), 4, B, L, None, NOISE_PHILOX, 1, 0, None,
                                 ptr(samp), None, s))
 
     def f_copy():
