@@ -103,6 +103,52 @@ __device__ __forceinline__ void group_argmax(T& v, int& i) {
   if constexpr (G >= 64) argmax_step<32>(v, i);
 }
 
+template <int G>
+__device__ __forceinline__ int group_min(int v) {
+  if constexpr (G >= 2) v = min(v, partner<1>(v));
+  if constexpr (G >= 4) v = min(v, partner<2>(v));
+  if constexpr (G >= 8) v = min(v, partner<4>(v));
+  if constexpr (G >= 16) v = min(v, partner<8>(v));
+  if constexpr (G >= 32) v = min(v, partner<16>(v));
+  if constexpr (G >= 64) v = min(v, partner<32>(v));
+  return v;
+}
+
+// Inclusive prefix sum over the lanes of a group, in lane order (g = lane index in the group).
+template <int G, typename T>
+__device__ __forceinline__ T group_scan_inclusive(T v, int g) {
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    const T up = __shfl_up(v, d, 64);
+    if (g >= d) v += up;
+  }
+  return v;
+}
+
+// One draw from the categorical distribution with unnormalised weights w over a
+// token's classes (w = 0 on masked slots), from ONE uniform u in [0,1) shared by
+// the group: inverse CDF over the classes in (lane, slot) order.  V slots per
+// lane; `cls(g, v)` maps a slot to its class.  Every lane returns the class.
+template <int G, int V, typename T, typename ClsFn>
+__device__ __forceinline__ int group_pick(const T (&w)[V], int g, T u, int fallback, ClsFn cls) {
+  T lane_tot = 0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) lane_tot += w[v];
+  const T incl = group_scan_inclusive<G>(lane_tot, g);
+  const int lane = threadIdx.x & 63;
+  const T total = __shfl(incl, (lane & ~(G - 1)) + (G - 1), 64);
+  const T target = u * total;
+  T run = incl - lane_tot;
+  int key = 0x7fffffff;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    run += w[v];
+    if (key == 0x7fffffff && w[v] > 0 && target < run) key = g * V + v;
+  }
+  key = group_min<G>(key);
+  return key == 0x7fffffff ? fallback : cls(key / V, key % V);
+}
+
 // Sum over the whole wave, result valid in every lane.
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return group_sum<64>(v); }
@@ -145,6 +191,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id
 }
 // U[0,1) with 24 random bits, like torch.rand for float32.
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }
+// U[0,1) with 53 random bits.
+__device__ __forceinline__ double u01d_open(uint32_t hi, uint32_t lo) {
+  uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
+  return (double)m * 1.1102230246251565e-16;
+}
 // U(0,1] with 53 random bits.
 __device__ __forceinline__ double u01d(uint32_t hi, uint32_t lo) {
   uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;

@@ -101,6 +101,74 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
   }
 }
 
+// ------------------------------------------------------------------ q_sample, device noise, structured tables
+// The reference samples x_t by Gumbel-max over softmax(log(q + eps)), i.e. from
+// weights w_j = q(x_t = j | x0) + eps.  With column structure those weights are
+// off_j + eps for every j except x0, so with noise drawn on the device one
+// uniform per token suffices: inverse CDF over the prefix sums of (off + eps),
+// kept in LDS per workgroup (one timestep), with the x0 entry spliced in.  One
+// thread per token, 16 bytes of traffic per token.
+__global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t seed, uint64_t offset,
+                                                         const uint64_t* __restrict__ offset_dev,
+                                                         int64_t* __restrict__ out) {
+  __shared__ float cdf[257];     // cdf[j] = sum_{i<j} (off_i + eps)
+  __shared__ float dmo[256];     // diag_j - off_j
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  if (offset_dev) offset += *offset_dev;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int t = load_tok(a.t, b, a.t_bytes);
+  const float* dgd_ = dg(a.tb.qbar_digest, t, 0, K);
+  const float* dgo_ = dg(a.tb.qbar_digest, t, 1, K);
+  if (threadIdx.x < 64) {        // one wave scans K <= 256 weights, four per lane
+    const int l = threadIdx.x;
+    float w[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * l + i;
+      w[i] = j < K ? dgo_[j] + eps : 0.0f;
+      s += w[i];
+    }
+    const float incl = group_scan_inclusive<64>(s, l);
+    float run = incl - s;
+    if (l == 0) cdf[0] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * l + i;
+      run += w[i];
+      if (j < K) cdf[j + 1] = run;
+    }
+  }
+  for (int j = threadIdx.x; j < K; j += blockDim.x) dmo[j] = dgd_[j] - dgo_[j];
+  __syncthreads();
+  const float total = cdf[K];
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + threadIdx.x; pos < p1; pos += blockDim.x) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const U4 r4 = philox4x32_10((uint64_t)n, offset, seed);
+    const float extra = dmo[x0];
+    const double r = u01d_open(r4.x, r4.y) * ((double)total + (double)extra);
+    const double lo = cdf[x0], hi = (double)cdf[x0 + 1] + (double)extra;
+    int j;
+    if (r >= lo && r < hi) {
+      j = x0;
+    } else {
+      const float rr = (float)(r < lo ? r : r - (double)extra);
+      // largest j with cdf[j] <= rr, j in [0, K-1]
+      int l = 0, h = K;          // invariant: cdf[l] <= rr < cdf[h] (up to rounding at the ends)
+      while (h - l > 1) {
+        const int mid = (l + h) >> 1;
+        if (cdf[mid] <= rr) l = mid; else h = mid;
+      }
+      j = l;
+      // rounding at the splice can land on x0's generic slot: move to the side r came from
+      if (j == x0) j = (r < lo) ? (x0 > 0 ? x0 - 1 : x0) : (x0 + 1 < K ? x0 + 1 : x0);
+    }
+    out[n] = j;
+  }
+}
+
 // ------------------------------------------------------------------ posterior pieces
 // Everything a token needs from the digests, for t > 0.
 template <class L>
@@ -214,7 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_logits(ImgArgs a, const flo
 constexpr float LOG2E = 1.44269504088896340736f;
 // rows in flight per lane group: 64 bytes per lane whatever the layout
 template <class L> constexpr int pipe_depth() { return L::V >= 8 ? 2 : 4; }
-template <class L> constexpr int loss_max_threads() { return L::V >= 8 ? 512 : 1024; }
+template <class L> constexpr int loss_max_threads() { return 1024; }
 constexpr int MAX_WAVES = 16;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -656,6 +724,12 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
   hipStream_t s = (hipStream_t)stream;
   if (!tb->structured)
     return dense_q_sample(tb, x0, tok_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, offset_dev, x_t, s);
+  if (noise_kind == D3PM_NOISE_PHILOX) {
+    ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, 1);    // one thread per token
+    hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev, x_t);
+    D3PM_LAUNCH_CHECK("k_q_sample_icdf");
+    return D3PM_OK;
+  }
   return dispatch_layout(tb->K, noise_kind == D3PM_NOISE_PHILOX || aligned16(noise), [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);

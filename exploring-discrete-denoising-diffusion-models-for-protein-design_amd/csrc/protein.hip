@@ -29,22 +29,6 @@ __device__ __forceinline__ void load_digest_d(const double* digest, int t, int c
   load_slots<L>(dgd(digest, t, c, K), g, K, 0.0, out);
 }
 
-// Exp(1) draws for one lane's slots: passed in, or Philox.
-template <class L>
-__device__ __forceinline__ void load_expo(const double* expo, long n, int K, int g, uint64_t seed, uint64_t offset,
-                                          double (&e)[L::V]) {
-  if (expo) {
-    load_slots<L>(expo + n * K, g, K, 1.0, e);
-  } else {
-    static_assert(L::V <= 4, "two Philox calls cover four slots");
-    const U4 r0 = philox4x32_10(((uint64_t)n * L::G + g) * 2, offset, seed);
-    const U4 r1 = philox4x32_10(((uint64_t)n * L::G + g) * 2 + 1, offset, seed);
-    const double u[4] = {u01d(r0.x, r0.y), u01d(r0.z, r0.w), u01d(r1.x, r1.y), u01d(r1.z, r1.w)};
-#pragma unroll
-    for (int v = 0; v < L::V; ++v) e[v] = -log(u[v]);
-  }
-}
-
 // ------------------------------------------------------------------ forward corruption
 template <class L>
 __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __restrict__ expo, uint64_t seed,
@@ -61,19 +45,32 @@ __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
     const int x0 = (int)a.x0[n];
-    double e[L::V];
-    load_expo<L>(expo, n, K, g, seed, offset, e);
-    double best = -INFINITY;
-    int besti = 0x7fffffff;
+    double pv[L::V];
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
       const int c = L::cls(g, v);
-      const double p = (c == x0) ? d[v] : o[v];
-      if (probs && c < K) probs[n * K + c] = p;
-      const double val = p / e[v];
-      if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+      pv[v] = (c < K) ? ((c == x0) ? d[v] : o[v]) : 0.0;
+      if (probs && c < K) probs[n * K + c] = pv[v];
     }
-    group_argmax<L::G>(best, besti);
+    int besti;
+    if (expo) {
+      // the reference's draw: torch.multinomial on CPU = argmax_j(p_j / E_j), E ~ Exp(1) passed in
+      double e[L::V];
+      load_slots<L>(expo + n * K, g, K, 1.0, e);
+      double best = -INFINITY;
+      besti = 0x7fffffff;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const int c = L::cls(g, v);
+        const double val = pv[v] / e[v];
+        if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+      }
+      group_argmax<L::G>(best, besti);
+    } else {
+      // device noise: one uniform per token, inverse CDF (same distribution, K times fewer draws)
+      const U4 r = philox4x32_10((uint64_t)n, offset, seed);
+      besti = group_pick<L::G, L::V>(pv, g, u01d_open(r.x, r.y), x0, [](int gg, int vv) { return L::cls(gg, vv); });
+    }
     if (g == 0) x_t[n] = besti;
   }
 }
@@ -256,16 +253,24 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
     softmax_f32_to_f64<L>(z, g, K, p);
     const double a_diag = dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = dgd(a.tb.qone_digest, t, 1, K)[xt];
     marginal<L>(p, md, mo, a_diag, a_off, xt, g, K, A, r, rsum);
-    load_expo<L>(expo, n, K, g, seed, offset, e);
-    double best = -INFINITY;
-    int besti = 0x7fffffff;
+    int besti;
+    if (expo) {
+      // the reference's draw: torch.multinomial on CPU = argmax_j(P_j / E_j), E ~ Exp(1) passed in
+      load_slots<L>(expo + n * K, g, K, 1.0, e);
+      double best = -INFINITY;
+      besti = 0x7fffffff;
 #pragma unroll
-    for (int v = 0; v < L::V; ++v) {
-      const int c = L::cls(g, v);
-      const double val = (r[v] / rsum) / e[v];
-      if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+      for (int v = 0; v < L::V; ++v) {
+        const int c = L::cls(g, v);
+        const double val = (r[v] / rsum) / e[v];
+        if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+      }
+      group_argmax<L::G>(best, besti);
+    } else {
+      // device noise: one uniform per token, inverse CDF over the unnormalised marginal
+      const U4 rn = philox4x32_10((uint64_t)n, offset, seed);
+      besti = group_pick<L::G, L::V>(r, g, u01d_open(rn.x, rn.y), xt, [](int gg, int vv) { return L::cls(gg, vv); });
     }
-    group_argmax<L::G>(best, besti);
     if (g == 0) out[n] = besti;
   }
 }

@@ -256,3 +256,26 @@ def test_full_size_properties(pkg):
         (loss_ref.sum() / B).backward()
         ref = lg_ref.grad.numpy()
         close(g[sl], ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_q_sample_device_noise_distribution(pkg):
+    """With noise drawn on the device q_sample uses one uniform per token
+    (inverse CDF); its empirical distribution must be softmax(log(q + eps))."""
+    K, T = 32, 500
+    betas = pkg.generate_betas(0, 0, T, "jsd")
+    for kind in ("uniform", "absorbing"):
+        d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=5, transition_bands=None,
+                                  model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                  hybrid_coeff=0.001, device=DEV)
+        for tval, x0val in ((3, 5), (250, 16), (499, 31), (40, 0)):
+            B, L = 64, 8192
+            x0 = torch.full((B, L), x0val, device=DEV)
+            t = torch.full((B,), tval, dtype=torch.int32, device=DEV)
+            torch.manual_seed(21)
+            xt = d.q_sample(x0, t)
+            n = xt.numel()
+            freq = torch.bincount(xt.flatten().cpu(), minlength=K).numpy() / n
+            q = d.q_probs(x0[:1, :1], t[:1]).cpu().numpy().reshape(K).astype(np.float64) + 1e-6
+            q /= q.sum()
+            tol = 5 * np.sqrt(q * (1 - q) / n) + 2e-6
+            assert (np.abs(freq - q) < tol).all(), (kind, tval, freq, q)

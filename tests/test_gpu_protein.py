@@ -149,3 +149,29 @@ def test_non_uniform_tables_fail_loudly(pkg):
     Q = torch.rand(5, 22, 22, dtype=torch.float64, device=DEV)
     with pytest.raises(NotImplementedError):
         protein_tables(Q, Q)
+
+
+def test_reverse_step_device_noise_distribution(pkg, tables500):
+    """Device-noise mode draws with one uniform per token (inverse CDF): the
+    empirical class frequencies must match the oracle's marginal."""
+    from d3pm_amd.protein_generation.generate import reverse_step
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    tb = protein_tables(Qt, Qb)
+    gen = torch.Generator().manual_seed(5)
+    for t in (400, 3):
+        logits1 = torch.randn(1, 24, generator=gen) * 1.5
+        # (two identical positions: the oracle's squeeze() needs more than one)
+        P = pr.reverse_marginal(logits1.expand(2, 24), torch.tensor([7, 7]), Qt.cpu()[t], Qb.cpu()[t - 1])[0].numpy()
+        Bn, Ln = 64, 4096
+        logits = logits1.expand(Bn, Ln, 24).contiguous().to(DEV)
+        x = torch.full((Bn, Ln), 7, device=DEV)
+        torch.manual_seed(11)
+        out = reverse_step(tb, logits, x, torch.full((Bn,), t, device=DEV))
+        torch.manual_seed(11)
+        again = reverse_step(tb, logits, x, torch.full((Bn,), t, device=DEV))
+        assert torch.equal(out, again)
+        n = out.numel()
+        freq = torch.bincount(out.flatten().cpu(), minlength=22).numpy() / n
+        tol = 5 * np.sqrt(P * (1 - P) / n) + 1e-5
+        assert (np.abs(freq - P) < tol).all(), (freq, P)
