@@ -12,14 +12,19 @@ namespace d3pm {
 
 constexpr int next_pow2_c(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <class L>
+// MFMA = true: K = 256 only; the contraction runs on v_mfma_f32_32x32x2_f32 over
+// tiles of 32 tokens whose LDS rows are padded by 16 bytes (conflict-free
+// ds_read_b128 of the A fragments).
+template <class L, bool MFMA = false>
 struct DenseCfg {
   static constexpr int TPP = BLOCK / L::G;              // tokens per epilogue pass
-  static constexpr int TM = TPP > 16 ? TPP : 16;        // tokens per tile
+  static constexpr int TM = MFMA ? 32 : (TPP > 16 ? TPP : 16);   // tokens per tile
+  static constexpr int PAD = MFMA ? 4 : 0;              // floats of padding per LDS row
   static constexpr int KC = next_pow2_c(L::G * L::V);   // threads per token group in the contraction
   static constexpr int CG = BLOCK / KC;                 // token groups
   static constexpr int TPT = TM / CG;                   // tokens per thread
   static_assert(TM % CG == 0 && TPT >= 1, "tile does not split over the workgroup");
+  static_assert(TM % TPP == 0, "tile is a whole number of epilogue passes");
 };
 
 // ------------------------------------------------------------------ gathers only
@@ -163,6 +168,81 @@ __device__ __forceinline__ void tile_contract(const float* __restrict__ M, int K
   }
 }
 
+// The same contraction for K = 256 on the matrix cores, exact float32
+// (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain).  Four waves; wave w owns
+// output columns [64w, 64w+64) of all TM rows: TM/32 x 2 accumulator tiles of
+// 32 x 32.  The 256-long reduction is split over the two lane halves as
+// k = 128 h + s, so a lane's A operands for four consecutive steps s are one
+// 16-byte LDS read and its B operands are coalesced 128-byte row pieces of M,
+// read straight from global memory (every wave needs different columns, so LDS
+// staging of M would add traffic, not save it) one group of four steps ahead.
+// `in` and `out` are LDS [TM][260]; they may be the same buffer.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TM>
+__device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ M, const float* in, float* out) {
+  constexpr int K = 256, LDK = K + 4, RT = TM / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+  const float* bcol = M + (size_t)(128 * h) * K + 64 * wave + r;      // M[128h + s][64w + r (+32)]
+  const float* arow = in + (size_t)r * LDK + 128 * h;                 // in[r (+32 rt)][128h + s]
+  // groups of GS reduction steps; the B operands of the next group are requested
+  // before the current group's MFMAs (GS * RT * 2 * 64 cycles of cover)
+  constexpr int GS = 8, NG = 128 / GS;
+  auto load_b = [&](float (&b)[GS][2], int grp) {
+#pragma unroll
+    for (int q = 0; q < GS; ++q) {
+      b[q][0] = bcol[(size_t)(grp * GS + q) * K];
+      b[q][1] = bcol[(size_t)(grp * GS + q) * K + 32];
+    }
+  };
+  auto compute = [&](const float (&b)[GS][2], int grp) {
+    float4 av[RT][GS / 4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int f = 0; f < GS / 4; ++f)
+        av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + grp * GS + 4 * f);
+#pragma unroll
+    for (int q = 0; q < GS; ++q) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 a4 = av[rt][q / 4];
+        const float aq = (q % 4) == 0 ? a4.x : ((q % 4) == 1 ? a4.y : ((q % 4) == 2 ? a4.z : a4.w));
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, b[q][ct], acc[rt][ct], 0, 0, 0);
+      }
+    }
+  };
+  float b0[GS][2], b1[GS][2];
+  load_b(b0, 0);
+#pragma unroll 1
+  for (int grp = 0; grp < NG; grp += 2) {
+    load_b(b1, grp + 1);
+    compute(b0, grp);
+    if (grp + 2 < NG) load_b(b0, grp + 2);
+    compute(b1, grp + 1);
+  }
+  __syncthreads();     // every wave has read its A operands: `out` may alias `in`
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;      // C/D layout of the 32x32 MFMA
+        out[(size_t)row * LDK + 64 * wave + 32 * ct + r] = acc[rt][ct][e];
+      }
+}
+
 enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
 
 struct DenseExtra {
@@ -175,16 +255,19 @@ struct DenseExtra {
   const float* noise; uint64_t seed, offset; const uint64_t* offset_dev; int64_t* sample;
 };
 
-template <class L, int MODE, bool GRAD, int NOISE>
+template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
 __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
-  using C = DenseCfg<L>;
+  using C = DenseCfg<L, MFMA>;
   extern __shared__ float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
   const int K = a.tb.K;
+  const int LDK = K + C::PAD;              // LDS row stride
   const float eps = a.tb.eps;
-  float* s_pi = lds;                       // [TM][K] softmax(z)
-  float* s_f2 = lds + (size_t)C::TM * K;   // [TM][K] pi @ Qm, later d loss / d f2
-  float* s_gp = s_f2 + (size_t)C::TM * K;  // [TM][K] d loss / d pi (GRAD only)
+  float* s_pi = lds;                         // [TM][LDK] softmax(z)
+  float* s_f2 = lds + (size_t)C::TM * LDK;   // [TM][LDK] pi @ Qm, later d loss / d f2
+  // d loss / d pi (GRAD only): its own buffer, or on the matrix-core path the
+  // buffer of d loss / d f2, which the contraction has consumed by then
+  float* s_gp = MFMA ? s_f2 : s_f2 + (size_t)C::TM * LDK;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
   const int t = load_tok(a.t, b, a.t_bytes);
@@ -219,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
       for (int v = 0; v < L::V; ++v) {
         zkeep[ps][v] = z[v];
         const int c = L::cls(g, v);
-        if (c < K) s_pi[(size_t)tok * K + c] = live ? pi[v] : 0.0f;
+        if (c < K) s_pi[(size_t)tok * LDK + c] = live ? pi[v] : 0.0f;
       }
       cekeep[ps] = 0;
       if constexpr (MODE == DENSE_LOSS) {
@@ -236,7 +319,10 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
     }
     __syncthreads();
     // ---- phase 2: f2 = pi @ Qbar_{t-1}
-    if (need_post) tile_contract<L>(Qm, K, s_pi, s_f2);
+    if (need_post) {
+      if constexpr (MFMA) tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
+      else tile_contract<L>(Qm, K, s_pi, s_f2);
+    }
     __syncthreads();
     // ---- phase 3: per-token epilogue
 #pragma unroll
@@ -252,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           const int c = L::cls(g, v);
-          f2e[v] = (c < K ? s_f2[(size_t)tok * K + c] : 1.0f) + eps;
+          f2e[v] = (c < K ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
           lm[v] = logf(f1[v] + eps) + logf(f2e[v]);
         }
       }
@@ -325,7 +411,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
             for (int v = 0; v < L::V; ++v) {
               const int c = L::cls(g, v);
               const float gm = (em[v] * ism - et[v] * ist) * w_vb;
-              if (c < K) s_f2[(size_t)tok * K + c] = live ? gm / f2e[v] : 0.0f;
+              if (c < K) s_f2[(size_t)tok * LDK + c] = live ? gm / f2e[v] : 0.0f;
             }
           }
         }
@@ -335,7 +421,10 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
     if constexpr (MODE == DENSE_LOSS && GRAD) {
       __syncthreads();
       // ---- phase 4: d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T
-      if (need_post) tile_contract<L>(QmT, K, s_f2, s_gp);
+      if (need_post) {
+        if constexpr (MFMA) tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
+        else tile_contract<L>(QmT, K, s_f2, s_gp);
+      }
       __syncthreads();
       // ---- phase 5: through the softmax of z, plus the CE term
 #pragma unroll
@@ -349,14 +438,14 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           const int c = L::cls(g, v);
-          pi[v] = c < K ? s_pi[(size_t)tok * K + c] : 0.0f;
+          pi[v] = c < K ? s_pi[(size_t)tok * LDK + c] : 0.0f;
         }
         if (need_post) {
           float gp[L::V], dot = 0;
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
             const int c = L::cls(g, v);
-            gp[v] = c < K ? s_gp[(size_t)tok * K + c] : 0.0f;
+            gp[v] = c < K ? s_gp[(size_t)tok * LDK + c] : 0.0f;
             dot += pi[v] * gp[v];
           }
           dot = group_sum<L::G>(dot);
@@ -390,13 +479,40 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
 }
 
 // ------------------------------------------------------------------ host side
-template <class L>
+template <class L, bool MFMA>
 static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0b, const void* xt, int xtb, const void* t,
                                int tb_, int B, long npos) {
   ImgArgs a = make_args(tb, x0, x0b, xt, xtb, t, tb_, B, npos, L::G);
-  const TokenGrid tg = token_grid(B, npos, DenseCfg<L>::TM);
+  const TokenGrid tg = token_grid(B, npos, DenseCfg<L, MFMA>::TM);
   a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
   return a;
+}
+
+// The matrix-core contraction is built for K = 256 in the 64-lane vector layout.
+template <class L>
+constexpr bool mfma_layout() { return L::VEC && L::G == 64 && L::V == 4; }
+
+template <class L, class F>
+static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
+  static const bool allow = !(getenv("D3PM_NO_MFMA") && atoi(getenv("D3PM_NO_MFMA")));
+  if constexpr (mfma_layout<L>()) {
+    if (allow && tb->K == 256) return f(std::true_type{});
+  }
+  return f(std::false_type{});
+}
+
+template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
+static int launch_tile(const d3pm_tables_f32* tb, const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
+  using C = DenseCfg<L, MFMA>;
+  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * ((GRAD && !MFMA) ? 3 : 2);
+  auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA>;
+  if (sh > 48 * 1024) {
+    hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }
+  hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(BLOCK), sh, s, a, e);
+  D3PM_LAUNCH_CHECK("k_dense_tile");
+  return D3PM_OK;
 }
 
 static int dense_q_probs(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, const void* t, int t_bytes, int B,
@@ -432,11 +548,6 @@ static int dense_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_byt
   });
 }
 
-template <class L>
-static size_t dense_lds_bytes(int K, bool grad) {
-  return (size_t)DenseCfg<L>::TM * K * sizeof(float) * (grad ? 3 : 2);
-}
-
 static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start, int x_start_is_logits, long ld,
                                   int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes, int B,
                                   long npos, float* out, hipStream_t s) {
@@ -450,44 +561,41 @@ static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start
       D3PM_LAUNCH_CHECK("k_dense_posterior_tokens");
       return D3PM_OK;
     }
-    ImgArgs a = make_dense_args<L>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
-    DenseExtra e{};
-    e.logits = (const float*)x_start; e.ld = ld; e.out = out;
-    hipLaunchKernelGGL((k_dense_tile<L, DENSE_POST, false, D3PM_NOISE_GUMBEL>), dim3(B * a.chunks), dim3(BLOCK),
-                       dense_lds_bytes<L>(tb->K, false), s, a, e);
-    D3PM_LAUNCH_CHECK("k_dense_tile<POST>");
-    return D3PM_OK;
+    return with_mfma_choice<L>(tb, [&](auto mf) {
+      constexpr bool MF = decltype(mf)::value;
+      ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
+      DenseExtra e{};
+      e.logits = (const float*)x_start; e.ld = ld; e.out = out;
+      return launch_tile<L, DENSE_POST, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
+    });
   });
 }
 
 static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
                              const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos, int loss_type,
                              float hybrid_coeff, float grad_scale, const float* grad_out, float* vb, float* ce,
-                             float* loss,
-                             float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                             float* loss, float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
   D3PM_CHECK_ARG(!dlogits || tb->qbarT, "dense backward needs the transposed cumulative table (qbarT)");
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits)) && aligned16(tb->qbar) &&
                    aligned16(tb->qoneT);
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
-    ImgArgs a = make_dense_args<L>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
-    const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
-    DenseExtra e{};
-    e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale; e.grad_out = grad_out;
-    e.part = (float*)workspace; e.dlogits = dlogits;
-    const dim3 grid(B * a.chunks), block(BLOCK);
-    if (dlogits)
-      hipLaunchKernelGGL((k_dense_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL>), grid, block,
-                         dense_lds_bytes<L>(tb->K, true), s, a, e);
-    else
-      hipLaunchKernelGGL((k_dense_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL>), grid, block,
-                         dense_lds_bytes<L>(tb->K, false), s, a, e);
-    D3PM_LAUNCH_CHECK("k_dense_tile<LOSS>");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{vb, ce, loss, e.part}, B,
-                       a.chunks, npos, loss_type, hybrid_coeff, 1.0f / LN2);
-    D3PM_LAUNCH_CHECK("k_loss_finalize");
-    return D3PM_OK;
+    return with_mfma_choice<L>(tb, [&](auto mf) {
+      constexpr bool MF = decltype(mf)::value;
+      ImgArgs a = make_dense_args<L, MF>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
+      const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      DenseExtra e{};
+      e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
+      e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
+      const int rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s)
+                             : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{vb, ce, loss, e.part}, B,
+                         a.chunks, npos, loss_type, hybrid_coeff, 1.0f / LN2);
+      D3PM_LAUNCH_CHECK("k_loss_finalize");
+      return D3PM_OK;
+    });
   });
 }
 
@@ -499,19 +607,16 @@ static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long l
                    (!probs || aligned16(probs)) && aligned16(tb->qbar) && aligned16(tb->qoneT);
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
-    ImgArgs a = make_dense_args<L>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
-    DenseExtra e{};
-    e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.offset_dev = offset_dev; e.sample = sample; e.probs = probs;
-    const dim3 grid(B * a.chunks), block(BLOCK);
-    const size_t sh = dense_lds_bytes<L>(tb->K, false);
-    if (noise_kind == D3PM_NOISE_UNIFORM)
-      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_UNIFORM>), grid, block, sh, s, a, e);
-    else if (noise_kind == D3PM_NOISE_GUMBEL)
-      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_GUMBEL>), grid, block, sh, s, a, e);
-    else
-      hipLaunchKernelGGL((k_dense_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_PHILOX>), grid, block, sh, s, a, e);
-    D3PM_LAUNCH_CHECK("k_dense_tile<SAMPLE>");
-    return D3PM_OK;
+    return with_mfma_choice<L>(tb, [&](auto mf) {
+      constexpr bool MF = decltype(mf)::value;
+      ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
+      DenseExtra e{};
+      e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.offset_dev = offset_dev;
+      e.sample = sample; e.probs = probs;
+      if (noise_kind == D3PM_NOISE_UNIFORM) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_UNIFORM, MF>(tb, a, e, B, s);
+      if (noise_kind == D3PM_NOISE_GUMBEL) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
+      return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_PHILOX, MF>(tb, a, e, B, s);
+    });
   });
 }
 

@@ -12,6 +12,7 @@
 #include "layout.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace d3pm {
 

@@ -37,8 +37,10 @@ def main():
     ap.add_argument("--kind", default="uniform")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, L, K, T = a.B, a.L, 2 ** a.bits, 500
-    d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0, 0, T, "jsd"), transition_mat_type=a.kind,
+    B, L, K = a.B, a.L, 2 ** a.bits
+    T = 1000 if a.kind == "gaussian" else 500
+    betas = d3pm_amd.generate_betas(1e-4, 0.02, T, "linear") if a.kind == "gaussian" else d3pm_amd.generate_betas(0, 0, T, "jsd")
+    d = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type=a.kind,
                                    num_bits=a.bits, transition_bands=None, model_prediction="x_start",
                                    model_output="logits", loss_type="hybrid", hybrid_coeff=0.001, device=dev)
     tb = d.tables()
@@ -84,7 +86,8 @@ def main():
                                     ("scale_rows early exit (launch floor)", f_noop, 0)):
         us = timeit(fn, a.reps)
         print(f"{name:32s} {us:8.2f} us  {N / us * 1e-3:8.2f} Gtok/s  {bytes_per_tok * N / us * 1e-3:8.1f} GB/s "
-              f"({bytes_per_tok * N / us * 1e-3 / 8000 * 100:5.1f}% of 8 TB/s)")
+              f"({bytes_per_tok * N / us * 1e-3 / 8000 * 100:5.1f}% of 8 TB/s)  dense-contraction "
+              f"{4 * K * K * N / us * 1e-6:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
