@@ -256,10 +256,11 @@ struct DenseExtra {
 };
 
 template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
-__global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
+__global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, DenseExtra e) {
   using C = DenseCfg<L, MFMA>;
   extern __shared__ float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
+  __shared__ int s_x0[C::TM], s_xt[C::TM];   // the tile's tokens (clean, noisy)
   const int K = a.tb.K;
   const int LDK = K + C::PAD;              // LDS row stride
   const float eps = a.tb.eps;
@@ -289,14 +290,20 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
     // ---- phase 1: softmax of the tile's logits into LDS, CE term
     float zkeep[C::TM / C::TPP][L::V];   // logits of this lane's tokens (only used at t == 0 / POST)
     float cekeep[C::TM / C::TPP];
-#pragma unroll
+    // (the next pass's row is requested before this pass computes)
+    float zn[L::V];
+    auto row_of = [&](int tk) { const long ps_ = tile0 + tk; return (long)b * a.npos + (ps_ < p1 ? ps_ : tile0); };
+    load_slots<L>(e.logits + row_of(slot) * e.ld, g, K, -INFINITY, zn);
+#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
     for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
       const int tok = ps * C::TPP + slot;
       const long pos = tile0 + tok;
       float z[L::V], pi[L::V], zmax = 0, zsum = 1;
       const bool live = pos < p1;
-      const long n = (long)b * a.npos + (live ? pos : tile0);
-      load_slots<L>(e.logits + n * e.ld, g, K, -INFINITY, z);
+      const long n = row_of(tok);
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) z[v] = zn[v];
+      if (ps + 1 < C::TM / C::TPP) load_slots<L>(e.logits + row_of(tok + C::TPP) * e.ld, g, K, -INFINITY, zn);
       group_softmax<L>(z, pi, zmax, zsum);
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
@@ -305,8 +312,10 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
         if (c < K) s_pi[(size_t)tok * LDK + c] = live ? pi[v] : 0.0f;
       }
       cekeep[ps] = 0;
+      if (g == 0) s_xt[tok] = load_tok(a.xt, n, a.xt_bytes);
       if constexpr (MODE == DENSE_LOSS) {
         const int x0 = load_tok(a.x0, n, a.x0_bytes);
+        if (g == 0) s_x0[tok] = x0;
         float zx0 = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0) ? z[v] : 0.0f;
@@ -325,13 +334,65 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
     }
     __syncthreads();
     // ---- phase 3: per-token epilogue
+    if constexpr (MODE == DENSE_LOSS) {
+      // kl = sum_j q_j log(q_j / p_j) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of
+      // Qbar_{t-1} + eps, f2 = pi Qbar_{t-1} + eps): the reference's softmax(log a + log .) pairs folded, one
+      // log per class (of a ratio close to one where q is large).  The two table rows of the next pass are
+      // requested before this pass computes.
+      float f1n[L::V], f2n[L::V];
+      auto gather = [&](int tk) {
+        load_slots<L>(a.tb.qoneT + ((size_t)t * K + s_xt[tk]) * K, g, K, 0.0f, f1n);
+        load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + s_x0[tk]) * K, g, K, 0.0f, f2n);
+      };
+      if (need_post) gather(slot);
+#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
+      for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+        const int tok = ps * C::TPP + slot;
+        const bool live = tile0 + tok < p1;
+        const float ce = cekeep[ps];
+        float vb = ce;
+        if (need_post) {
+          float av[L::V], bv[L::V];
 #pragma unroll
+          for (int v = 0; v < L::V; ++v) { av[v] = f1n[v] + eps; bv[v] = f2n[v] + eps; }
+          if (ps + 1 < C::TM / C::TPP) gather(tok + C::TPP);
+          float f2e[L::V], em[L::V], qu[L::V], zm = 0, zt = 0;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            const bool ok = c < K;
+            f2e[v] = (ok ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
+            em[v] = ok ? av[v] * f2e[v] : 0.0f;
+            qu[v] = ok ? av[v] * bv[v] : 0.0f;
+            zm += em[v];
+            zt += qu[v];
+          }
+          zm = group_sum<L::G>(zm);
+          zt = group_sum<L::G>(zt);
+          const float izm = 1.0f / zm, izt = 1.0f / zt, zr = zm * izt;
+          float kl = 0;
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            const float rf = __builtin_amdgcn_rcpf(f2e[v]);
+            kl = fmaf(qu[v], __builtin_amdgcn_logf(bv[v] * rf * zr), kl);      // log2; qu = 0 on masked slots
+            if constexpr (GRAD) {
+              const float gf2 = w_vb * av[v] * (izm - bv[v] * rf * izt);
+              if (c < K) s_f2[(size_t)tok * LDK + c] = live ? gf2 : 0.0f;
+            }
+          }
+          vb = group_sum<L::G>(kl) * izt * LN2;                                  // nats, like ce
+        }
+        if (g == 0 && live) { acc_vb += vb; acc_ce += ce; }
+      }
+    } else
+#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
     for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
       const int tok = ps * C::TPP + slot;
       const long pos = tile0 + tok;
       const bool live = pos < p1;
       const long n = (long)b * a.npos + (live ? pos : tile0);
-      const int xt = load_tok(a.xt, n, a.xt_bytes);
+      const int xt = s_xt[tok];
       float f1[L::V], lm[L::V], f2e[L::V];
       if (need_post) {
         load_slots<L>(a.tb.qoneT + ((size_t)t * K + xt) * K, g, K, 0.0f, f1);
@@ -427,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_tile(ImgArgs a, DenseExtra e) {
       }
       __syncthreads();
       // ---- phase 5: through the softmax of z, plus the CE term
-#pragma unroll
+#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
       for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
         const int tok = ps * C::TPP + slot;
         const long pos = tile0 + tok;
