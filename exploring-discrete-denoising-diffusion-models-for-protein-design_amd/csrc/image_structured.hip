@@ -304,6 +304,32 @@ __device__ __forceinline__ void write_losses(const LossOut& o, int b, float svb,
   if (o.loss) o.loss[b] = loss_type == D3PM_LOSS_KL ? v : (loss_type == D3PM_LOSS_CE ? c_ : v + hybrid_coeff * c_);
 }
 
+// Debug builds (-DD3PM_TIMELINE) record the 100 MHz wall clock at a few points of
+// the first and last wave of every workgroup; d3pm_debug_timeline copies them out.
+#ifdef D3PM_TIMELINE
+constexpr int TL_POINTS = 9;
+__device__ unsigned long long g_timeline[256][16][TL_POINTS];
+#define D3PM_TL_DECL unsigned long long tl_[TL_POINTS] = {}
+#ifdef D3PM_TL_SHADERCLK
+#define D3PM_CLK() __builtin_amdgcn_s_memtime()
+#else
+#define D3PM_CLK() wall_clock64()
+#endif
+#define D3PM_TL(i) tl_[i] = D3PM_CLK()
+// waits until the register holds its loaded value, then records the clock
+#define D3PM_TL_AFTER(i, reg) do { asm volatile("" ::"v"(reg)); tl_[i] = D3PM_CLK(); } while (0)
+#define D3PM_TL_FLUSH                                                                                    \
+  do {                                                                                                   \
+    if (blockIdx.x < 256 && (threadIdx.x & 63) == 0)                                                     \
+      for (int i_ = 0; i_ < TL_POINTS; ++i_) g_timeline[blockIdx.x][threadIdx.x >> 6][i_] = tl_[i_];     \
+  } while (0)
+#else
+#define D3PM_TL_DECL do {} while (0)
+#define D3PM_TL(i) do {} while (0)
+#define D3PM_TL_AFTER(i, reg) do {} while (0)
+#define D3PM_TL_FLUSH do {} while (0)
+#endif
+
 template <class L, bool GRAD>
 __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
     ImgArgs a, const float* __restrict__ logits, long ld, int loss_type, float hybrid_coeff, float grad_scale,
@@ -332,8 +358,11 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
   // Start-up order: the timestep (a scalar load), then the few digest rows that
   // depend on it, then the first rows of logits; vector loads return in issue
   // order, so the digests must not queue behind the row burst.
+  D3PM_TL_DECL;
+  D3PM_TL(0);
   const int t = load_tok(a.t, b, a.t_bytes);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
+  D3PM_TL_AFTER(1, t);
   float bdo[L::V], boe[L::V], bo[L::V];
   float sum_boe = 0, sum_bo = 0;
   float f_ad = 0, f_ao = 0, f_d = 0, f_o = 0;
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
 
   // per-class constants of Qbar_{t-1} for this lane's slots, and their sums over all classes
   if (need_post) {
+    D3PM_TL_AFTER(2, bo[L::V - 1]);
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
       const bool ok = L::VEC || L::cls(g, v) < K;
@@ -390,6 +420,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
     }
     __syncthreads();
   }
+  D3PM_TL(3);
   if (pbeg < p1) issue_special(0, pbeg);
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
@@ -397,6 +428,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
   const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
   const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
   float acc_vb = 0, acc_ce = 0;          // per-lane partial sums, in bits; lane 0 of a group carries the token
+  D3PM_TL_AFTER(4, w_ce);
   for (unsigned pos0 = pbeg; pos0 < p1; pos0 += PIPE * tpp) {
 #pragma unroll
     for (int u = 0; u < PIPE; ++u) {
@@ -408,6 +440,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
       float z[L::V];
 #pragma unroll
       for (int v = 0; v < L::V; ++v) z[v] = zz[u][v];
+      if (u == 0 && pos0 == pbeg) D3PM_TL_AFTER(5, z_xt);
       {                                  // special classes of the next stage, then refill this stage's slot
         const unsigned nxt1 = pos + tpp, nxt = pos + PIPE * tpp;
         if (nxt1 < p1) issue_special((u + 1) % PIPE, nxt1);
@@ -506,8 +539,10 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
         store_slots_off<L>(drow, pos * row_bytes, g, K, gz);
         if (!L::VEC && ld > K) zero_tail<L>(reinterpret_cast<float*>(drow + (size_t)pos * row_bytes), g, K, ld);
       }
+      if (u == 0 && pos0 == pbeg) D3PM_TL(6);
     }
   }
+  D3PM_TL(7);
   // workgroup sums (fixed order: lanes by butterfly, waves in index order)
   acc_vb = wave_sum(acc_vb);
   acc_ce = wave_sum(acc_ce);
@@ -524,7 +559,14 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
       out.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
     }
   }
+  D3PM_TL(8);
+  D3PM_TL_FLUSH;
 }
+#ifdef D3PM_TIMELINE
+extern "C" int d3pm_debug_timeline(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline), sizeof(g_timeline));
+}
+#endif
 
 // Sums of the per-workgroup partials in chunk order; `unit` converts them to
 // bits (1 for partials already in bits, 1/ln2 for partials in nats).
@@ -814,7 +856,7 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
     // directly; small batches are split over chunks and summed by k_loss_finalize.
     int block = BLOCK;
     if (B >= 192) {
-      static const int tpg = getenv("D3PM_TOKENS_PER_GROUP") ? atoi(getenv("D3PM_TOKENS_PER_GROUP")) : 8;
+      static const int tpg = getenv("D3PM_TOKENS_PER_GROUP") ? atoi(getenv("D3PM_TOKENS_PER_GROUP")) : 4;
       long want = ((npos + tpg - 1) / tpg) * L::G;       // lane groups make ~tpg trips each
       want = ((want + 63) / 64) * 64;
       const long cap = loss_max_threads<L>();
