@@ -191,7 +191,9 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-  const float* bcol = M + (size_t)(128 * h) * K + 64 * wave + r;      // M[128h + s][64w + r (+32)]
+  // M[128h + s][64w + r (+32)] through the wave-uniform base and a 32-bit byte offset
+  const char* Mb = reinterpret_cast<const char*>(M);
+  const unsigned boff = (unsigned)(((128 * h) * K + 64 * wave + r) * 4);
   const float* arow = in + (size_t)r * LDK + 128 * h;                 // in[r (+32 rt)][128h + s]
   // groups of GS reduction steps; the B operands of the next group are requested
   // before the current group's MFMAs (GS * RT * 2 * 64 cycles of cover)
@@ -199,17 +201,19 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
   auto load_b = [&](float (&b)[GS][2], int grp) {
 #pragma unroll
     for (int q = 0; q < GS; ++q) {
-      b[q][0] = bcol[(size_t)(grp * GS + q) * K];
-      b[q][1] = bcol[(size_t)(grp * GS + q) * K + 32];
+      const unsigned o = boff + (unsigned)((grp * GS + q) * K * 4);
+      b[q][0] = *reinterpret_cast<const float*>(Mb + o);
+      b[q][1] = *reinterpret_cast<const float*>(Mb + (o + 128u));
     }
   };
-  auto compute = [&](const float (&b)[GS][2], int grp) {
-    float4 av[RT][GS / 4];
+  auto load_a = [&](float4 (&av)[RT][GS / 4], int grp) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int f = 0; f < GS / 4; ++f)
         av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + grp * GS + 4 * f);
+  };
+  auto compute = [&](const float4 (&av)[RT][GS / 4], const float (&b)[GS][2]) {
 #pragma unroll
     for (int q = 0; q < GS; ++q) {
 #pragma unroll
@@ -222,14 +226,33 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
       }
     }
   };
+  // Both operand streams are double-buffered by hand.  Each half trip is scheduled as
+  // one MFMA, one global load, one MFMA, ... so that issuing the next group's loads
+  // hides under the matrix pipe instead of in front of it.
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < GS * 2 * RT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      if (i < RT * GS / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
   float b0[GS][2], b1[GS][2];
+  float4 a0[RT][GS / 4], a1[RT][GS / 4];
   load_b(b0, 0);
+  load_a(a0, 0);
 #pragma unroll 1
   for (int grp = 0; grp < NG; grp += 2) {
     load_b(b1, grp + 1);
-    compute(b0, grp);
-    if (grp + 2 < NG) load_b(b0, grp + 2);
-    compute(b1, grp + 1);
+    load_a(a1, grp + 1);
+    compute(a0, b0);
+    interleave();
+    const int nxt = grp + 2 < NG ? grp + 2 : grp;     // unconditional (a repeat on the last trip): exact wait counts
+    load_b(b0, nxt);
+    load_a(a0, nxt);
+    compute(a1, b1);
+    interleave();
   }
   __syncthreads();     // every wave has read its A operands: `out` may alias `in`
 #pragma unroll
@@ -246,6 +269,7 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
 enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
 
 struct DenseExtra {
+  int B;
   const float* logits; long ld;
   // loss
   int loss_type; float hybrid_coeff; float grad_scale; const float* grad_out; float* part; float* dlogits;
@@ -260,7 +284,6 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   using C = DenseCfg<L, MFMA>;
   extern __shared__ float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
-  __shared__ int s_x0[C::TM], s_xt[C::TM];   // the tile's tokens (clean, noisy)
   const int K = a.tb.K;
   const int LDK = K + C::PAD;              // LDS row stride
   const float eps = a.tb.eps;
@@ -269,9 +292,16 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   // d loss / d pi (GRAD only): its own buffer, or on the matrix-core path the
   // buffer of d loss / d f2, which the contraction has consumed by then
   float* s_gp = MFMA ? s_f2 : s_f2 + (size_t)C::TM * LDK;
-  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  // Workgroups are dealt to the 8 XCDs round-robin by index; all chunks of a batch
+  // element go to the same XCD so that its two 256 KB matrices (one timestep) are
+  // fetched into one L2 only.  The grid is B rounded up to a multiple of 8.
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int b = (within / a.chunks) * 8 + xcd, chunk = within % a.chunks;
+  if (b >= e.B) return;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  // vector layouts cover exactly K classes: no masked slots
+  auto valid = [&](int c) { return L::VEC || c < K; };
+  const int t = __builtin_amdgcn_readfirstlane(load_tok(a.t, b, a.t_bytes));   // one timestep per workgroup
   const bool need_post = (t > 0) && !(MODE == DENSE_LOSS && e.loss_type == D3PM_LOSS_CE);
   const float* Qm = need_post ? a.tb.qbar + (size_t)(t - 1) * K * K : nullptr;
   const float* QmT = (need_post && GRAD) ? a.tb.qbarT + (size_t)(t - 1) * K * K : nullptr;
@@ -286,228 +316,215 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   float acc_vb = 0, acc_ce = 0;
   if (MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX && e.offset_dev) e.offset += *e.offset_dev;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+#ifdef D3PM_TIMELINE
+  // debug builds: time spent per phase, summed over this wave's tiles (slot 0: start, 6: end)
+  unsigned long long ph_[TL_POINTS] = {}, last_ = wall_clock64();
+  ph_[0] = last_;
+#define D3PM_PHASE(i) do { const unsigned long long now_ = wall_clock64(); ph_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define D3PM_PHASE(i) do {} while (0)
+#endif
+  // A lane group keeps the same tokens through all phases of a tile (token ps * TPP + slot in pass ps), so
+  // their indices stay in registers.  Global reads run ahead of their use by a whole phase: a tile's logits rows
+  // and tokens are requested during the previous tile's second contraction (or before its first, without a
+  // backward pass), the table rows of the epilogue before the first contraction.
+  constexpr int NP = C::TM / C::TPP;       // passes per phase
+  float zn[NP][L::V];
+  int x0n[NP], xtn[NP];
+  auto fetch_tile = [&](long tile) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long pos = tile + ps * C::TPP + slot;
+      const long n = (long)b * a.npos + (pos < p1 ? pos : tile);
+      load_slots<L>(e.logits + n * e.ld, g, K, -INFINITY, zn[ps]);
+      xtn[ps] = load_tok(a.xt, n, a.xt_bytes);
+      x0n[ps] = (MODE == DENSE_LOSS) ? load_tok(a.x0, n, a.x0_bytes) : 0;
+    }
+  };
+  fetch_tile(chunk * a.chunk_pos);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += C::TM) {
     // ---- phase 1: softmax of the tile's logits into LDS, CE term
-    float zkeep[C::TM / C::TPP][L::V];   // logits of this lane's tokens (only used at t == 0 / POST)
-    float cekeep[C::TM / C::TPP];
-    // (the next pass's row is requested before this pass computes)
-    float zn[L::V];
-    auto row_of = [&](int tk) { const long ps_ = tile0 + tk; return (long)b * a.npos + (ps_ < p1 ? ps_ : tile0); };
-    load_slots<L>(e.logits + row_of(slot) * e.ld, g, K, -INFINITY, zn);
-#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
-    for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
-      const int tok = ps * C::TPP + slot;
-      const long pos = tile0 + tok;
-      float z[L::V], pi[L::V], zmax = 0, zsum = 1;
-      const bool live = pos < p1;
-      const long n = row_of(tok);
+    float zkeep[NP][L::V];   // logits of this lane's tokens (only used at t == 0 / POST)
+    float cekeep[NP];
+    int x0c[NP], xtc[NP];
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) z[v] = zn[v];
-      if (ps + 1 < C::TM / C::TPP) load_slots<L>(e.logits + row_of(tok + C::TPP) * e.ld, g, K, -INFINITY, zn);
-      group_softmax<L>(z, pi, zmax, zsum);
+    for (int ps = 0; ps < NP; ++ps) {
+      const int tok = ps * C::TPP + slot;
+      const bool live = tile0 + tok < p1;
+      x0c[ps] = x0n[ps]; xtc[ps] = xtn[ps];
+      float pi[L::V];
+      float m = zn[ps][0];
+#pragma unroll
+      for (int v = 1; v < L::V; ++v) m = fmaxf(m, zn[ps][v]);
+      m = group_max<L::G>(m);
+      float sum = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((zn[ps][v] - m) * LOG2E); sum += pi[v]; }   // 0 on masked slots
+      sum = group_sum<L::G>(sum);
+      const float inv = fast_rcp(sum);
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        zkeep[ps][v] = z[v];
+        zkeep[ps][v] = zn[ps][v];
         const int c = L::cls(g, v);
-        if (c < K) s_pi[(size_t)tok * LDK + c] = live ? pi[v] : 0.0f;
+        if (valid(c)) s_pi[(size_t)tok * LDK + c] = live ? pi[v] * inv : 0.0f;
       }
       cekeep[ps] = 0;
-      if (g == 0) s_xt[tok] = load_tok(a.xt, n, a.xt_bytes);
       if constexpr (MODE == DENSE_LOSS) {
-        const int x0 = load_tok(a.x0, n, a.x0_bytes);
-        if (g == 0) s_x0[tok] = x0;
         float zx0 = 0;
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0) ? z[v] : 0.0f;
+        for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0c[ps]) ? zn[ps][v] : 0.0f;
         zx0 = group_sum<L::G>(zx0);
-        cekeep[ps] = (zmax + logf(zsum)) - zx0;
+        cekeep[ps] = fmaf(fast_log2(sum), LN2, m) - zx0;
       }
       if constexpr (MODE == DENSE_SAMPLE) {
-        if (e.probs && live) store_slots<L>(e.probs + n * K, g, K, pi);
+        if (e.probs && live) {
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) pi[v] *= inv;
+          const long n = (long)b * a.npos + tile0 + tok;
+          store_slots<L>(e.probs + n * K, g, K, pi);
+        }
       }
     }
+    // table rows of the epilogue: column x_t of Q_t and (loss only) row x0 of Qbar_{t-1}; those of the first
+    // pass are requested here, ahead of the contraction, the others one pass ahead
+    float f1n[NP][L::V], f2n[NP][L::V];
+    auto gather = [&](int ps) {
+      load_slots<L>(a.tb.qoneT + ((size_t)t * K + xtc[ps]) * K, g, K, 0.0f, f1n[ps]);
+      if constexpr (MODE == DENSE_LOSS)
+        load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + x0c[ps]) * K, g, K, 0.0f, f2n[ps]);
+    };
+    if (need_post) gather(0);
+    const bool more = tile0 + C::TM < p1;
+    if (!GRAD && more) fetch_tile(tile0 + C::TM);
     __syncthreads();
+    D3PM_PHASE(1);
     // ---- phase 2: f2 = pi @ Qbar_{t-1}
     if (need_post) {
       if constexpr (MFMA) tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
       else tile_contract<L>(Qm, K, s_pi, s_f2);
     }
     __syncthreads();
+    D3PM_PHASE(2);
     // ---- phase 3: per-token epilogue
-    if constexpr (MODE == DENSE_LOSS) {
-      // kl = sum_j q_j log(q_j / p_j) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of
-      // Qbar_{t-1} + eps, f2 = pi Qbar_{t-1} + eps): the reference's softmax(log a + log .) pairs folded, one
-      // log per class (of a ratio close to one where q is large).  The two table rows of the next pass are
-      // requested before this pass computes.
-      float f1n[L::V], f2n[L::V];
-      auto gather = [&](int tk) {
-        load_slots<L>(a.tb.qoneT + ((size_t)t * K + s_xt[tk]) * K, g, K, 0.0f, f1n);
-        load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + s_x0[tk]) * K, g, K, 0.0f, f2n);
-      };
-      if (need_post) gather(slot);
-#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
-      for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
-        const int tok = ps * C::TPP + slot;
-        const bool live = tile0 + tok < p1;
-        const float ce = cekeep[ps];
-        float vb = ce;
-        if (need_post) {
-          float av[L::V], bv[L::V];
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) { av[v] = f1n[v] + eps; bv[v] = f2n[v] + eps; }
-          if (ps + 1 < C::TM / C::TPP) gather(tok + C::TPP);
-          float f2e[L::V], em[L::V], qu[L::V], zm = 0, zt = 0;
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
-            const bool ok = c < K;
-            f2e[v] = (ok ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
-            em[v] = ok ? av[v] * f2e[v] : 0.0f;
-            qu[v] = ok ? av[v] * bv[v] : 0.0f;
-            zm += em[v];
-            zt += qu[v];
-          }
-          zm = group_sum<L::G>(zm);
-          zt = group_sum<L::G>(zt);
-          const float izm = 1.0f / zm, izt = 1.0f / zt, zr = zm * izt;
-          float kl = 0;
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
-            const float rf = __builtin_amdgcn_rcpf(f2e[v]);
-            kl = fmaf(qu[v], __builtin_amdgcn_logf(bv[v] * rf * zr), kl);      // log2; qu = 0 on masked slots
-            if constexpr (GRAD) {
-              const float gf2 = w_vb * av[v] * (izm - bv[v] * rf * izt);
-              if (c < K) s_f2[(size_t)tok * LDK + c] = live ? gf2 : 0.0f;
-            }
-          }
-          vb = group_sum<L::G>(kl) * izt * LN2;                                  // nats, like ce
-        }
-        if (g == 0 && live) { acc_vb += vb; acc_ce += ce; }
-      }
-    } else
-#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
-    for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+    for (int ps = 0; ps < NP; ++ps) {
       const int tok = ps * C::TPP + slot;
       const long pos = tile0 + tok;
       const bool live = pos < p1;
       const long n = (long)b * a.npos + (live ? pos : tile0);
-      const int xt = s_xt[tok];
-      float f1[L::V], lm[L::V], f2e[L::V];
+      float f2e[L::V];
       if (need_post) {
-        load_slots<L>(a.tb.qoneT + ((size_t)t * K + xt) * K, g, K, 0.0f, f1);
+        if (ps + 1 < NP) gather(ps + 1);
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           const int c = L::cls(g, v);
-          f2e[v] = (c < K ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
-          lm[v] = logf(f1[v] + eps) + logf(f2e[v]);
+          f2e[v] = (valid(c) ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
         }
       }
-      if constexpr (MODE == DENSE_POST) {
-        float r[L::V];
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps][v] : lm[v];
-        if (live) store_slots<L>(e.out + n * K, g, K, r);
-      } else if constexpr (MODE == DENSE_SAMPLE) {
-        float best = -INFINITY;
-        int besti = 0x7fffffff;
-        float u[L::V];
-        if (t > 0) {
-          if constexpr (NOISE == D3PM_NOISE_PHILOX) {
-            const U4 r = philox4x32_10((uint64_t)n * L::G + g, e.offset, e.seed);
-            const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int v = 0; v < L::V; ++v) u[v] = u01(rr[v]);
-          } else {
-            load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
-          }
-        }
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          const int c = L::cls(g, v);
-          float val;
-          if (t == 0) val = zkeep[ps][v];
-          else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]));
-          if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
-        }
-        group_argmax<L::G>(best, besti);
-        if (g == 0 && live) e.sample[n] = besti;
-      } else {  // DENSE_LOSS
-        const int x0 = load_tok(a.x0, n, a.x0_bytes);
+      if constexpr (MODE == DENSE_LOSS) {
+        // kl = sum_j q_j log(q_j / p_j) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of
+        // Qbar_{t-1} + eps, f2 = pi Qbar_{t-1} + eps): the reference's softmax(log a + log .) pairs folded, one
+        // log per class (of a ratio close to one where q is large).
         const float ce = cekeep[ps];
         float vb = ce;
         if (need_post) {
-          float f2t[L::V], tl[L::V];
-          load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + x0) * K, g, K, 0.0f, f2t);
-          float mmax = -INFINITY, tmax = -INFINITY;
+          float av[L::V], bv[L::V], zm = 0, zt = 0;
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
-            const bool ok = L::cls(g, v) < K;
-            lm[v] = ok ? lm[v] + eps : -INFINITY;
-            tl[v] = ok ? (logf(f1[v] + eps) + logf(f2t[v] + eps)) + eps : -INFINITY;
-            mmax = fmaxf(mmax, lm[v]);
-            tmax = fmaxf(tmax, tl[v]);
+            const bool ok = valid(L::cls(g, v));
+            av[v] = ok ? f1n[ps][v] + eps : 0.0f;
+            bv[v] = f2n[ps][v] + eps;
+            zm = fmaf(av[v], f2e[v], zm);
+            zt = fmaf(av[v], bv[v], zt);
           }
-          mmax = group_max<L::G>(mmax);
-          tmax = group_max<L::G>(tmax);
-          float em[L::V], et[L::V], sm = 0, st = 0;
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            em[v] = expf(lm[v] - mmax); sm += em[v];
-            et[v] = expf(tl[v] - tmax); st += et[v];
-          }
-          sm = group_sum<L::G>(sm);
-          st = group_sum<L::G>(st);
-          const float lsm_off = mmax + logf(sm), lst_off = tmax + logf(st);
-          const float ism = 1.0f / sm, ist = 1.0f / st;
+          zm = group_sum<L::G>(zm);
+          zt = group_sum<L::G>(zt);
+          const float izm = fast_rcp(zm), izt = fast_rcp(zt), zr = zm * izt;
           float kl = 0;
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
-            const bool ok = L::cls(g, v) < K;
-            kl += ok ? (et[v] * ist) * ((tl[v] - lst_off) - (lm[v] - lsm_off)) : 0.0f;
-          }
-          vb = group_sum<L::G>(kl);
-          if constexpr (GRAD) {
-#pragma unroll
-            for (int v = 0; v < L::V; ++v) {
-              const int c = L::cls(g, v);
-              const float gm = (em[v] * ism - et[v] * ist) * w_vb;
-              if (c < K) s_f2[(size_t)tok * LDK + c] = live ? gm / f2e[v] : 0.0f;
+            const int c = L::cls(g, v);
+            const float br = bv[v] * fast_rcp(f2e[v]);                     // b_j / f2_j
+            kl = fmaf(av[v] * bv[v], fast_log2(br * zr), kl);              // av = 0 on masked slots
+            if constexpr (GRAD) {
+              const float gf2 = w_vb * av[v] * fmaf(-br, izt, izm);
+              if (valid(c)) s_f2[(size_t)tok * LDK + c] = live ? gf2 : 0.0f;
             }
           }
+          vb = group_sum<L::G>(kl) * izt * LN2;                            // nats, like ce
         }
         if (g == 0 && live) { acc_vb += vb; acc_ce += ce; }
+      } else {
+        float lm[L::V];
+        if (need_post) {
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) lm[v] = logf(f1n[ps][v] + eps) + logf(f2e[v]);
+        }
+        if constexpr (MODE == DENSE_POST) {
+          float r[L::V];
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps][v] : lm[v];
+          if (live) store_slots<L>(e.out + n * K, g, K, r);
+        } else {   // DENSE_SAMPLE
+          float best = -INFINITY;
+          int besti = 0x7fffffff;
+          float u[L::V];
+          if (t > 0) {
+            if constexpr (NOISE == D3PM_NOISE_PHILOX) {
+#pragma unroll
+              for (int h = 0; h < L::V / 4; ++h) {
+                const U4 r = philox4x32_10(((uint64_t)n * L::G + g) * (L::V / 4) + h, e.offset, e.seed);
+                u[4 * h + 0] = u01(r.x); u[4 * h + 1] = u01(r.y); u[4 * h + 2] = u01(r.z); u[4 * h + 3] = u01(r.w);
+              }
+            } else {
+              load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
+            }
+          }
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            float val;
+            if (t == 0) val = zkeep[ps][v];
+            else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]));
+            if (valid(c) && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+          }
+          group_argmax<L::G>(best, besti);
+          if (g == 0 && live) e.sample[n] = besti;
+        }
       }
     }
     if constexpr (MODE == DENSE_LOSS && GRAD) {
+      if (more) fetch_tile(tile0 + C::TM);
       __syncthreads();
+      D3PM_PHASE(3);
       // ---- phase 4: d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T
       if (need_post) {
         if constexpr (MFMA) tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
         else tile_contract<L>(QmT, K, s_f2, s_gp);
       }
       __syncthreads();
+      D3PM_PHASE(4);
       // ---- phase 5: through the softmax of z, plus the CE term
-#pragma unroll(MFMA ? 1 : C::TM / C::TPP)
-      for (int ps = 0; ps < C::TM / C::TPP; ++ps) {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
         const int tok = ps * C::TPP + slot;
         const long pos = tile0 + tok;
         if (pos >= p1) continue;     // whole lane groups leave together
         const long n = (long)b * a.npos + pos;
-        const int x0 = load_tok(a.x0, n, a.x0_bytes);
+        const int x0 = x0c[ps];
         float pi[L::V], gz[L::V];
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           const int c = L::cls(g, v);
-          pi[v] = c < K ? s_pi[(size_t)tok * LDK + c] : 0.0f;
+          pi[v] = valid(c) ? s_pi[(size_t)tok * LDK + c] : 0.0f;
         }
         if (need_post) {
           float gp[L::V], dot = 0;
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
             const int c = L::cls(g, v);
-            gp[v] = c < K ? s_gp[(size_t)tok * LDK + c] : 0.0f;
-            dot += pi[v] * gp[v];
+            gp[v] = valid(c) ? s_gp[(size_t)tok * LDK + c] : 0.0f;
+            dot = fmaf(pi[v], gp[v], dot);
           }
           dot = group_sum<L::G>(dot);
 #pragma unroll
@@ -523,7 +540,15 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       }
     }
     __syncthreads();   // LDS tiles are reused by the next tile
+    D3PM_PHASE(5);
   }
+#ifdef D3PM_TIMELINE
+  ph_[6] = wall_clock64();
+  ph_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);              // HW_REG_HW_ID
+  ph_[8] = __builtin_amdgcn_s_getreg((3 << 11) | 20);              // HW_REG_XCC_ID
+  if (blockIdx.x < 256 && (threadIdx.x & 63) == 0)
+    for (int i_ = 0; i_ < TL_POINTS; ++i_) g_timeline[blockIdx.x][threadIdx.x >> 6][i_] = ph_[i_];
+#endif
   if constexpr (MODE == DENSE_LOSS) {
     acc_vb = wave_sum(acc_vb);
     acc_ce = wave_sum(acc_ce);
@@ -549,29 +574,34 @@ static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0
   return a;
 }
 
-// The matrix-core contraction is built for K = 256 in the 64-lane vector layout.
-template <class L>
-constexpr bool mfma_layout() { return L::VEC && L::G == 64 && L::V == 4; }
+// The matrix-core contraction is built for K = 256.  Around it the per-token
+// phases run 16 lanes per token with interleaved 16-byte pieces (4 tokens per
+// wave, reductions inside a DPP row); f(layout, use_mfma) gets that layout, or
+// the caller's with the VALU contraction.
+using MfmaLayout = Layout<16, 16, true, true>;
 
 template <class L, class F>
 static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
   static const bool allow = !(getenv("D3PM_NO_MFMA") && atoi(getenv("D3PM_NO_MFMA")));
-  if constexpr (mfma_layout<L>()) {
-    if (allow && tb->K == 256) return f(std::true_type{});
+  if constexpr (L::VEC) {
+    if (allow && tb->K == 256) return f(MfmaLayout{}, std::true_type{});
   }
-  return f(std::false_type{});
+  return f(L{}, std::false_type{});
 }
 
 template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
 static int launch_tile(const d3pm_tables_f32* tb, const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   using C = DenseCfg<L, MFMA>;
-  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * ((GRAD && !MFMA) ? 3 : 2);
+  static const size_t lds_pad = getenv("D3PM_DENSE_LDS_PAD") ? (size_t)atoi(getenv("D3PM_DENSE_LDS_PAD")) : 0;   // tuning aid: lowers occupancy
+  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * ((GRAD && !MFMA) ? 3 : 2) + lds_pad;
   auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA>;
   if (sh > 48 * 1024) {
     hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   }
-  hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(BLOCK), sh, s, a, e);
+  DenseExtra ee = e;
+  ee.B = B;
+  hipLaunchKernelGGL(kern, dim3(((B + 7) / 8) * 8 * a.chunks), dim3(BLOCK), sh, s, a, ee);
   D3PM_LAUNCH_CHECK("k_dense_tile");
   return D3PM_OK;
 }
@@ -622,7 +652,8 @@ static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start
       D3PM_LAUNCH_CHECK("k_dense_posterior_tokens");
       return D3PM_OK;
     }
-    return with_mfma_choice<L>(tb, [&](auto mf) {
+    return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
+      using L = decltype(lay2);
       constexpr bool MF = decltype(mf)::value;
       ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
       DenseExtra e{};
@@ -641,7 +672,8 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
                    aligned16(tb->qoneT);
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
-    return with_mfma_choice<L>(tb, [&](auto mf) {
+    return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
+      using L = decltype(lay2);
       constexpr bool MF = decltype(mf)::value;
       ImgArgs a = make_dense_args<L, MF>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
@@ -668,7 +700,8 @@ static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long l
                    (!probs || aligned16(probs)) && aligned16(tb->qbar) && aligned16(tb->qoneT);
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
-    return with_mfma_choice<L>(tb, [&](auto mf) {
+    return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
+      using L = decltype(lay2);
       constexpr bool MF = decltype(mf)::value;
       ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
       DenseExtra e{};

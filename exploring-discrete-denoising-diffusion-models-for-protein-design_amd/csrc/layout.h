@@ -7,14 +7,22 @@
 
 namespace d3pm {
 
-template <int G_, int V_, bool VEC_>
+// QUAD (vector layouts only): the lane's 16-byte pieces are interleaved across the
+// group, piece h of lane g being classes 4 (g + G h) .. +3, so that one access
+// instruction of the group covers 16 G contiguous bytes (fully coalesced in
+// global memory and conflict-free in LDS) however many classes a lane holds.
+template <int G_, int V_, bool VEC_, bool QUAD_ = false>
 struct Layout {
   static constexpr int G = G_;        // lanes per token
   static constexpr int V = V_;        // class slots per lane
-  static constexpr bool VEC = VEC_;   // slots contiguous (one 16-byte access)
+  static constexpr bool VEC = VEC_;   // slots in 16-byte pieces
+  static constexpr bool QUAD = QUAD_;
   static constexpr int TOKENS_PER_WAVE = 64 / G_;
   static_assert(!VEC_ || V_ % 4 == 0, "vector layouts hold whole 16-byte pieces");
-  __device__ static __forceinline__ int cls(int g, int v) { return VEC_ ? V_ * g + v : g + G_ * v; }
+  static_assert(!QUAD_ || VEC_, "interleaved pieces are a vector layout");
+  // first class of the lane's 16-byte piece h
+  __device__ static __forceinline__ int piece(int g, int h) { return QUAD_ ? 4 * (g + G_ * h) : V_ * g + 4 * h; }
+  __device__ static __forceinline__ int cls(int g, int v) { return VEC_ ? piece(g, v >> 2) + (v & 3) : g + G_ * v; }
 };
 
 // Load one token's slots of a float row; masked slots read `fill`.
@@ -23,7 +31,7 @@ __device__ __forceinline__ void load_slots(const float* __restrict__ row, int g,
   if constexpr (L::VEC) {
 #pragma unroll
     for (int h = 0; h < L::V / 4; ++h) {
-      const float4 q = *reinterpret_cast<const float4*>(row + L::V * g + 4 * h);
+      const float4 q = *reinterpret_cast<const float4*>(row + L::piece(g, h));
       z[4 * h + 0] = q.x; z[4 * h + 1] = q.y; z[4 * h + 2] = q.z; z[4 * h + 3] = q.w;
     }
   } else {
@@ -52,7 +60,7 @@ __device__ __forceinline__ void load_slots_off(const char* __restrict__ base, un
   if constexpr (L::VEC) {
 #pragma unroll
     for (int h = 0; h < L::V / 4; ++h) {
-      const float4 q = *reinterpret_cast<const float4*>(base + (row_off + 4u * L::V * (unsigned)g + 16u * h));
+      const float4 q = *reinterpret_cast<const float4*>(base + (row_off + 4u * (unsigned)L::piece(g, h)));
       z[4 * h + 0] = q.x; z[4 * h + 1] = q.y; z[4 * h + 2] = q.z; z[4 * h + 3] = q.w;
     }
   } else {
@@ -69,7 +77,7 @@ __device__ __forceinline__ void store_slots_off(char* __restrict__ base, unsigne
   if constexpr (L::VEC) {
 #pragma unroll
     for (int h = 0; h < L::V / 4; ++h)
-      *reinterpret_cast<float4*>(base + (row_off + 4u * L::V * (unsigned)g + 16u * h)) =
+      *reinterpret_cast<float4*>(base + (row_off + 4u * (unsigned)L::piece(g, h))) =
           make_float4(z[4 * h + 0], z[4 * h + 1], z[4 * h + 2], z[4 * h + 3]);
   } else {
 #pragma unroll
@@ -85,7 +93,7 @@ __device__ __forceinline__ void store_slots(float* __restrict__ row, int g, int 
   if constexpr (L::VEC) {
 #pragma unroll
     for (int h = 0; h < L::V / 4; ++h)
-      *reinterpret_cast<float4*>(row + L::V * g + 4 * h) =
+      *reinterpret_cast<float4*>(row + L::piece(g, h)) =
           make_float4(z[4 * h + 0], z[4 * h + 1], z[4 * h + 2], z[4 * h + 3]);
   } else {
 #pragma unroll
