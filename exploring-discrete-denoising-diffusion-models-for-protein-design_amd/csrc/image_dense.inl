@@ -317,6 +317,9 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   if (MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX && e.offset_dev) e.offset += *e.offset_dev;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
 #ifdef D3PM_TIMELINE
+#ifndef D3PM_TL_FIRST
+#define D3PM_TL_FIRST 0      // first of the 256 workgroups whose clocks are kept
+#endif
   // debug builds: time spent per phase, summed over this wave's tiles (slot 0: start, 6: end)
   unsigned long long ph_[TL_POINTS] = {}, last_ = wall_clock64();
   ph_[0] = last_;
@@ -546,8 +549,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   ph_[6] = wall_clock64();
   ph_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);              // HW_REG_HW_ID
   ph_[8] = __builtin_amdgcn_s_getreg((3 << 11) | 20);              // HW_REG_XCC_ID
-  if (blockIdx.x < 256 && (threadIdx.x & 63) == 0)
-    for (int i_ = 0; i_ < TL_POINTS; ++i_) g_timeline[blockIdx.x][threadIdx.x >> 6][i_] = ph_[i_];
+  if (blockIdx.x >= D3PM_TL_FIRST && blockIdx.x < D3PM_TL_FIRST + 256 && (threadIdx.x & 63) == 0)
+    for (int i_ = 0; i_ < TL_POINTS; ++i_) g_timeline[blockIdx.x - D3PM_TL_FIRST][threadIdx.x >> 6][i_] = ph_[i_];
 #endif
   if constexpr (MODE == DENSE_LOSS) {
     acc_vb = wave_sum(acc_vb);
@@ -569,7 +572,9 @@ template <class L, bool MFMA>
 static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0b, const void* xt, int xtb, const void* t,
                                int tb_, int B, long npos) {
   ImgArgs a = make_args(tb, x0, x0b, xt, xtb, t, tb_, B, npos, L::G);
-  const TokenGrid tg = token_grid(B, npos, DenseCfg<L, MFMA>::TM);
+  // matrix-core path: two workgroups per CU, two rounds of them over the chip (measured best of 512..4096)
+  static const int mfma_blocks = getenv("D3PM_DENSE_BLOCKS") ? atoi(getenv("D3PM_DENSE_BLOCKS")) : 1024;
+  const TokenGrid tg = token_grid(B, npos, DenseCfg<L, MFMA>::TM, MFMA ? mfma_blocks : 2048);
   a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
   return a;
 }

@@ -37,6 +37,10 @@ tl = buf[:, :4].astype(np.int64)
 names = ["", "1 softmax -> LDS", "2 contraction fwd", "3 epilogue (KL, d/df2)", "4 contraction bwd", "5 softmax bwd, store"]
 tot = (tl[:, :, 6] - tl[:, :, 0]) * 0.01
 print(f"first 256 workgroups; lifetime of a workgroup: median {np.median(tot):.1f} us")
+wg = tot[:, 0]
+print("lifetime percentiles (us): " + " ".join(f"p{q}={np.percentile(wg, q):.0f}" for q in (0, 10, 50, 90, 99, 100)))
+g0 = tl[:, :, 0].min()
+print(f"starts within {((tl[:, 0, 0] - g0) * 0.01).max():.1f} us; last end at {((tl[:, 0, 6] - g0) * 0.01).max():.1f} us")
 for i in range(1, 6):
     v = tl[:, :, i] * 0.01
     print(f"phase {names[i]:26s} median {np.median(v):7.2f} us  ({100 * np.median(v) / np.median(tot):4.1f}%)   per wave: "
