@@ -235,6 +235,7 @@ __global__ void k_lvb_finalize(const double* __restrict__ part, int B, int chunk
 template <class L>
 __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float* __restrict__ pred, long ld,
                                                         const double* __restrict__ expo, uint64_t seed, uint64_t offset,
+                                                        double last_class_div, long exclude_last_prefix,
                                                         int64_t* __restrict__ out) {
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
@@ -253,6 +254,9 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
     softmax_f32_to_f64<L>(z, g, K, p);
     const double a_diag = dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = dgd(a.tb.qone_digest, t, 1, K)[xt];
     marginal<L>(p, md, mo, a_diag, a_off, xt, g, K, A, r, rsum);
+    // MSA sampling (generate.py:84-88): the last class (the gap) is divided by 1 + penalty after the
+    // normalisation, and cannot be drawn at all in the first `exclude_last_prefix` positions (the query row)
+    const bool no_last = pos < exclude_last_prefix;
     int besti;
     if (expo) {
       // the reference's draw: torch.multinomial on CPU = argmax_j(P_j / E_j), E ~ Exp(1) passed in
@@ -262,12 +266,18 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
         const int c = L::cls(g, v);
-        const double val = (r[v] / rsum) / e[v];
-        if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+        double P = r[v] / rsum;
+        if (c == K - 1 && last_class_div != 1.0) P /= last_class_div;
+        const double val = P / e[v];
+        const bool ok = c < K && !(no_last && c == K - 1);
+        if (ok && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
       }
       group_argmax<L::G>(best, besti);
     } else {
       // device noise: one uniform per token, inverse CDF over the unnormalised marginal
+#pragma unroll
+      for (int v = 0; v < L::V; ++v)
+        if (L::cls(g, v) == K - 1) r[v] = no_last ? 0.0 : r[v] / last_class_div;
       const U4 rn = philox4x32_10((uint64_t)n, offset, seed);
       besti = group_pick<L::G, L::V>(r, g, u01d_open(rn.x, rn.y), xt, [](int gg, int vv) { return L::cls(gg, vv); });
     }
@@ -352,16 +362,18 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
 
 extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,
                                      const int64_t* t, int B, long npos, const double* expo, uint64_t seed,
-                                     uint64_t offset, int64_t* out, void* stream) {
+                                     uint64_t offset, double last_class_div, long exclude_last_prefix, int64_t* out,
+                                     void* stream) {
   if (int rc = check_prot(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(ld >= tb->K, "row stride %ld smaller than K=%d", ld, tb->K);
+  D3PM_CHECK_ARG(last_class_div > 0.0 && exclude_last_prefix >= 0, "last-class divisor must be positive, prefix >= 0");
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
   return dispatch_layout(tb->K, false, [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
     hipLaunchKernelGGL(k_lvb_reverse<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred, ld, expo,
-                       seed, offset, out);
+                       seed, offset, last_class_div, exclude_last_prefix, out);
     D3PM_LAUNCH_CHECK("k_lvb_reverse");
     return D3PM_OK;
   });

@@ -12,10 +12,13 @@ from .._lib import lib, check, ptr, stream_ptr
 from ..tables import protein_tables
 
 
-def reverse_step(tables, predictions, x_t, t, noise=None):
+def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, exclude_last_prefix=0):
     """x_{t-1} for a batch (generate.py:28-41): predictions [B,L,n_tokens]
     float32 logits, x_t [B,L] int64, t [B] int64; ``noise`` optionally the
-    Exp(1) draws [B,L,K] float64 of the reference's multinomial."""
+    Exp(1) draws [B,L,K] float64 of the reference's multinomial.  The last two
+    arguments are the MSA sampler's gap handling (generate.py:84-88): the last
+    class is divided by ``last_class_div`` and cannot be drawn in the first
+    ``exclude_last_prefix`` positions of each batch element."""
     from ..d3pm.diffusion_discrete import _philox_ticket
     _lib.require_device(predictions, x_t)
     pr = predictions.contiguous()
@@ -34,7 +37,8 @@ def reverse_step(tables, predictions, x_t, t, noise=None):
     out = torch.empty_like(x_t)
     with torch.cuda.device(x_t.device):
         check(lib.d3pm_lvb_reverse_step(tables.desc(), ptr(pr), pr.shape[-1], ptr(x_t), ptr(t), B, npos, ptr(noise),
-                                        seed, off, ptr(out), stream_ptr()))
+                                        seed, off, float(last_class_div), int(exclude_last_prefix), ptr(out),
+                                        stream_ptr()))
     return out
 
 
@@ -70,3 +74,59 @@ def sample_and_save(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, s
         for i, s in enumerate(strings):
             f.write(">SEQUENCE_" + str(i) + "\n" + str(s) + "\n")
     return strings
+
+
+def generate_msa_d3pm(model, batch_size, n_sequences, seq_length, device, timesteps=500, penalty_value=0, Q_bar=None,
+                      Q=None, tokenizer=None, start_query=True, query_sequence=None, x_init=None, noise_fn=None):
+    """Sample `batch_size` MSAs of `n_sequences` x `seq_length` tokens by T-1 reverse
+    steps (generate.py:48-99): returns (tokens [B,D,L] int64, [[string]] per MSA).
+
+    Per step the whole batch is one kernel launch over the D*L flattened positions:
+    the gap class (the last one) is divided by 1 + penalty_value and excluded from
+    the query row (the first L positions); with ``start_query`` the query row is
+    pinned to ``query_sequence`` (tokens [L]; the reference draws it from its
+    training MSA, generate.py:102-115, which is a data file this package does not
+    read).  ``x_init`` / ``noise_fn(step) -> [B, D*L, K]`` replay a recorded run;
+    in the noise of a replay the query-row rows hold the K-1 draws of the
+    reference's second multinomial call in their first K-1 columns."""
+    from .utils import Tokenizer
+    tokenizer = tokenizer or Tokenizer()
+    model.eval()
+    device = torch.device(device)
+    if x_init is None:
+        x_init = torch.randint(0, tokenizer.K, (batch_size, n_sequences, seq_length))
+    sample = x_init.to(torch.long).to(device).clone()
+    if start_query:
+        if query_sequence is None:
+            raise ValueError("start_query=True needs query_sequence (tokens of the query row)")
+        sample[:, 0] = torch.as_tensor(query_sequence, dtype=torch.long, device=device)
+    tables = protein_tables(Q, Q_bar, device=device)
+    # the divisor as the reference forms it: a float32 tensor of ones plus the penalty
+    div = float((torch.ones(1) + penalty_value).item())
+    steps = torch.linspace(timesteps - 1, 1, int((timesteps - 1) / 1), dtype=int).tolist()
+    with torch.no_grad():
+        for i, t in enumerate(steps):
+            tt = torch.full((sample.shape[0],), t, dtype=torch.long, device=device)
+            predictions = model(sample, tt)
+            nxt = reverse_step(tables, predictions.reshape(sample.shape[0], n_sequences * seq_length, -1),
+                               sample.reshape(sample.shape[0], -1), tt, None if noise_fn is None else noise_fn(i),
+                               last_class_div=div, exclude_last_prefix=seq_length).reshape(sample.shape)
+            if start_query:
+                nxt[:, 0] = sample[:, 0]
+            sample = nxt
+    flat = sample.reshape(sample.shape[0], -1).cpu()
+    return sample, [[tokenizer.untokenize(s)] for s in flat]
+
+
+def sample_and_save_msa(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, seq_len, device, batch_size,
+                        penalty_value, start_query=False, query_sequence=None):
+    """Generate `batch_size` MSAs of `num_seqs` sequences and append them to
+    ``generated_msas.a3m`` in the reference's record format (generate.py:133-150)."""
+    sample, string = generate_msa_d3pm(model, batch_size, num_seqs, seq_len, device, timesteps, penalty_value, Q_bar, Q,
+                                       tokenizer, start_query=start_query, query_sequence=query_sequence)
+    with open(out_path + "generated_msas.a3m", "a") as f:
+        for msa in string:
+            for seq in range(num_seqs):
+                seq_string = str(msa[0][seq * seq_len:(seq + 1) * seq_len]).replace("!", "")
+                f.write((">MSA_0" if seq == 0 else ">tr ") + "\n" + seq_string + "\n")
+    return sample, string

@@ -11,7 +11,7 @@ import torch
 from .. import _lib
 from .._lib import lib, check, ptr, stream_ptr
 from ..tables import ProteinTables
-from .constants import PROTEIN_ALPHABET, MSA_AAS, GAP
+from .constants import PROTEIN_ALPHABET, MSA_AAS, ALL_AAS, GAP
 
 
 def _default_device():
@@ -129,3 +129,125 @@ class Tokenizer(object):
 
     def undo_one_hot(self, x_onehot):
         return [np.where(r == 1)[0] for r in x_onehot]
+
+
+class CollaterV2(object):
+    """Collater with a caller-chosen timestep (utils.py:240-293), used by the
+    mutant scoring: __call__(data, t, noise=None) with data = [sequence, ...]
+    returns (src, src_one_hot, timesteps, tokenized, one_hot, Q, Q_bar, q_x), or
+    (src, timesteps, tokenized) when ``lean``.
+
+    t == num_steps corrupts with Q_bar[t-1].  The reference decrements its loop
+    variable after recording the first sequence's timestep (utils.py:277-280),
+    so it reports [t, t-1, t-1, ...]; ``reference_timesteps=True`` (the default)
+    keeps that, False reports t for every sequence."""
+
+    def __init__(self, tokenizer=None, num_steps=500, Q=None, Q_bar=None, device=None, lean=False,
+                 reference_timesteps=True):
+        self.tokenizer = tokenizer or Tokenizer()
+        self.num_steps = num_steps
+        self.K = self.tokenizer.K
+        self.Q = Q
+        self.Q_bar = Q_bar
+        self.device = torch.device(device) if device is not None else None
+        self.lean = lean
+        self.reference_timesteps = reference_timesteps
+
+    def __call__(self, data, t, noise=None):
+        from ..tables import protein_tables
+        dev = self.device if self.device is not None else (self.Q_bar.device if self.Q_bar.is_cuda else _default_device())
+        tok = np.stack([self.tokenizer.tokenize(s) for s in data]).astype(np.int64)
+        tokenized = torch.from_numpy(tok).to(dev)
+        B = tokenized.shape[0]
+        tc = t - 1 if t == self.num_steps else t
+        reported = [t] + [tc if self.reference_timesteps else t] * (B - 1)
+        timesteps = torch.tensor(reported, dtype=torch.long, device=dev)
+        tables = protein_tables(self.Q, self.Q_bar, device=dev)
+        src, q_x = corrupt_batch(tables, tokenized, torch.full((B,), tc, dtype=torch.long, device=dev), noise,
+                                 want_probs=not self.lean)
+        if self.lean:
+            return src, timesteps, tokenized
+        return (src, self.tokenizer.one_hot(src), timesteps, tokenized, self.tokenizer.one_hot(tokenized), self.Q,
+                self.Q_bar, q_x)
+
+
+def parse_mutants(input_path, focus_seq, focus_seq_name, focus_seq_trimmed):
+    """Sequences and descriptors of the valid mutants listed in a CSV
+    (utils.py:107-150): first line a header, first field of every other line
+    'A24C' or 'A24C:D30E' (wild type, 1-based position in the full protein,
+    mutant).  Upper-case letters of ``focus_seq`` are the modelled columns; the
+    name ends in '/<start>-<end>'.  Returns (sequences, descriptors) with the
+    wild type first."""
+    start_idx = int(focus_seq_name.split("/")[-1].split("-")[0])
+    table = {}
+    focus_idx = 0
+    for i, letter in enumerate(focus_seq):
+        if letter == letter.upper():
+            for mut in ALL_AAS:
+                if letter != mut:
+                    table[letter + str(start_idx + i) + mut] = focus_idx
+            focus_idx += 1
+    sequences = ["".join(focus_seq_trimmed)]
+    descriptors = ["wt"]
+    with open(input_path, "r") as f:
+        for i, line in enumerate(f):
+            if i == 0:
+                continue
+            mutants = line.rstrip().split(",")[0].split(":")
+            if all(m in table for m in mutants):
+                seq = list(focus_seq_trimmed)
+                for m in mutants:
+                    seq[table[m]] = m[-1]
+                sequences.append("".join(seq))
+                descriptors.append(":".join(mutants))
+    return np.array(sequences), descriptors
+
+
+def custom_mutant_matrix(input_path, model, device, focus_seq, focus_seq_name, focus_seq_trimmed, tokenizer, loss_func1,
+                         loss_func2, _lambda, timesteps, Q, Q_bar, N_pred_iterations=10, minibatch_size=2000,
+                         filename_prefix="", offset=0, noise_fn=None):
+    """ELBO difference of every listed mutant against the wild type
+    (utils.py:105-236): per repetition and mini-batch three evaluations of the
+    per-sequence LVB loss (t = 1; t ~ randint(2, T) weighted by T-1; t = T with
+    zero logits), averaged over ``N_pred_iterations`` repetitions.  Returns
+    (descriptors, delta_elbos), or writes ``<prefix>_samples-<N>_elbo_predictions.csv``.
+
+    ``loss_func1`` is a per-sequence loss (``D3PMLVBLoss(evaluation=True)``);
+    ``loss_func2``, ``_lambda`` and ``offset`` are accepted and unused, as in
+    the reference.  The shuffle and the random t come from numpy's global RNG in
+    the reference's order; ``noise_fn(iteration, batch_start, h) -> [B,L,K]``
+    replays the corruption draws.  Tokens are corrupted and scored on the
+    device; nothing but the strings is prepared on the host."""
+    sequences, descriptors = parse_mutants(input_path, focus_seq, focus_seq_name, focus_seq_trimmed)
+    n = sequences.shape[0]
+    prediction_matrix = np.zeros((n, N_pred_iterations))
+    batch_order = np.arange(n)
+    collater = CollaterV2(tokenizer=tokenizer, num_steps=timesteps, Q=Q, Q_bar=Q_bar, device=device)
+    steps = timesteps
+    model.eval()
+    with torch.no_grad():
+        for i in range(N_pred_iterations):
+            np.random.shuffle(batch_order)
+            for j in range(0, n, minibatch_size):
+                batch_index = batch_order[j:j + minibatch_size]
+                batch = sequences[batch_index]
+                losses = torch.zeros(batch_index.shape[0], device=device)
+                for h in range(3):
+                    t = 1 if h == 0 else (np.random.randint(2, steps) if h == 1 else steps)
+                    src, src_onehot, ts, tgt, tgt_onehot, Qc, Qbc, q = collater(
+                        batch, t, None if noise_fn is None else noise_fn(i, j, h))
+                    outputs = torch.zeros_like(src_onehot) if t == steps else model(src, ts)
+                    lvb_loss = loss_func1(src_onehot, q, outputs, tgt, tgt_onehot, ts, Qc, Qbc).to(torch.float32)
+                    if h == 1:
+                        lvb_loss = lvb_loss * (steps - 1)
+                    losses += lvb_loss
+                prediction_matrix[batch_index, i] = losses.cpu().numpy()
+    mean_elbos = np.mean(prediction_matrix, axis=1).flatten().tolist()
+    wt_elbo = mean_elbos.pop(0)
+    descriptors = descriptors[1:]
+    delta_elbos = -(np.asarray(mean_elbos) - wt_elbo)        # the losses are negative ELBOs
+    if filename_prefix == "":
+        return descriptors, delta_elbos
+    with open(filename_prefix + "_samples-" + str(N_pred_iterations) + "_elbo_predictions.csv", "w") as f:
+        for d, v in zip(descriptors, delta_elbos):
+            f.write(d + ";" + str(v) + "\n")

@@ -163,3 +163,88 @@ def generate(model, Q, Q_bar, timesteps: int, x_init: torch.Tensor, expo_fn, K: 
                 nxt[i] = torch.argmax(P / expo_fn(step, i), dim=1)
             sample = nxt
     return sample, [untokenize(s) for s in sample]
+
+
+def reverse_step_msa(logits: torch.Tensor, x_t: torch.Tensor, t: int, Q: torch.Tensor, Q_bar: torch.Tensor,
+                     expo_all: torch.Tensor, expo_query: torch.Tensor, penalty_value: float, start_query: bool,
+                     K: int = K_MSA) -> torch.Tensor:
+    """generate.py:70-93 for a batch of MSAs: logits [B,D,L,n_tokens], x_t
+    [B,D,L]; ``expo_all`` [B,D*L,K] and ``expo_query`` [B,L,K-1] are the draws of
+    the two ``torch.multinomial`` calls.  The gap class is divided by
+    1 + penalty (a float32 tensor in the reference) after normalisation; the
+    query row is drawn without the gap class; with ``start_query`` it is kept."""
+    B, D, L = x_t.shape
+    out = x_t.clone()
+    for i in range(B):
+        P = reverse_marginal(logits[i].flatten(0, 1), x_t[i].flatten(), Q[t], Q_bar[t - 1], K)
+        penalty = torch.ones(P.shape)
+        penalty[:, -1] += penalty_value
+        P = P / penalty
+        tmp = torch.argmax(P / expo_all[i], dim=1)
+        tmp[:L] = torch.argmax(P[:L, :-1] / expo_query[i], dim=1)
+        tmp = tmp.reshape(D, L)
+        if start_query:
+            out[i, 1:, :] = tmp[1:, :]
+        else:
+            out[i] = tmp
+    return out
+
+
+def generate_msa(model, Q, Q_bar, timesteps: int, x_init: torch.Tensor, expo_fn, penalty_value: float = 0.0,
+                 start_query: bool = False, K: int = K_MSA):
+    """generate.py:48-99: the MSA reverse loop from ``x_init`` [B,D,L];
+    ``expo_fn(step) -> (expo_all [B,D*L,K], expo_query [B,L,K-1])``."""
+    sample = x_init.clone()
+    B = sample.shape[0]
+    ts = torch.linspace(timesteps - 1, 1, int((timesteps - 1) / 1), dtype=int)
+    with torch.no_grad():
+        for step, t in enumerate(ts):
+            logits = model(sample, torch.tensor([t] * B))
+            ea, eq = expo_fn(step)
+            sample = reverse_step_msa(logits, sample, int(t), Q, Q_bar, ea, eq, penalty_value, start_query, K)
+    return sample, [[untokenize(s.flatten())] for s in sample]
+
+
+def collate_v2(tokens: torch.Tensor, t: int, num_steps: int, Q_bar: torch.Tensor, expo: torch.Tensor, K: int = K_MSA):
+    """utils.py:262-293 (``CollaterV2.__call__``) on tokenised sequences
+    [B,L] with the multinomial draws [B,L,K] passed in: returns (src [B,L],
+    timesteps [B], q_x [B,L,K]).  The loop variable is decremented after the
+    first sequence's timestep has been recorded when t == num_steps."""
+    src, ts, qx = [], [], []
+    for i in range(tokens.shape[0]):
+        ts.append(t)
+        if t == num_steps:
+            t = t - 1
+        x_t, p = corrupt(one_hot(tokens[i], K), Q_bar[t], expo[i])
+        src.append(x_t)
+        qx.append(p)
+    return torch.stack(src).to(torch.long), torch.tensor(ts, dtype=torch.long), torch.stack(qx).to(torch.double)
+
+
+def mutant_scores(tokens: torch.Tensor, model, Q, Q_bar, steps: int, n_iter: int, minibatch: int, order_fn, t_fn,
+                  expo_fn, K: int = K_MSA) -> np.ndarray:
+    """utils.py:152-222 (the scoring loop of ``custom_mutant_matrix``) on
+    tokenised sequences [N,L], wild type first: returns delta ELBOs [N-1].
+    ``order_fn(i)`` is the shuffled order of repetition i, ``t_fn(i, j)`` the
+    random middle timestep, ``expo_fn(i, j, h)`` the corruption draws."""
+    n = tokens.shape[0]
+    pm = np.zeros((n, n_iter))
+    with torch.no_grad():
+        for i in range(n_iter):
+            order = order_fn(i)
+            for j in range(0, n, minibatch):
+                idx = order[j:j + minibatch]
+                batch = tokens[idx]
+                losses = torch.zeros(len(idx))
+                for h in range(3):
+                    t = 1 if h == 0 else (t_fn(i, j) if h == 1 else steps)
+                    src, ts, q = collate_v2(batch, t, steps, Q_bar, expo_fn(i, j, h), K)
+                    src_oh, tgt_oh = one_hot(src, K), one_hot(batch, K)
+                    outputs = torch.zeros_like(src_oh) if t == steps else model(src, ts)
+                    l = lvb_per_sequence(src_oh, q, outputs, batch, tgt_oh, ts, Q, Q_bar, K=K, tmax=steps).to(torch.float32)
+                    if h == 1:
+                        l = l * (steps - 1)
+                    losses += l
+                pm[idx, i] = losses.numpy()
+    mean = pm.mean(axis=1)
+    return -(mean[1:] - mean[0])

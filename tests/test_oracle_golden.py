@@ -175,3 +175,69 @@ def test_protein_generate_replay():
     x = T_(g["x_init"])
     one = pr.reverse_step(model(x, torch.tensor([19] * 3)), x, 19, T_(g["Q_t"]), T_(g["Q_bar"]), expo[0])
     assert one.shape == x.shape
+
+
+def test_protein_generate_msa_replay():
+    g = golden("protein_generate_msa")
+    emb, tvec = T_(g["emb"]), T_(g["tvec"])
+    model = lambda x, tt: emb[x] + tvec[tt][:, None, None, :]
+    ea, eq = T_(g["expo_all"]), T_(g["expo_query"])
+    sample, strings = pr.generate_msa(model, T_(g["Q_t"]), T_(g["Q_bar"]), 12, T_(g["x_init"]),
+                                      lambda step: (ea[step], eq[step]), penalty_value=float(g["penalty"]))
+    np.testing.assert_array_equal(sample.numpy(), g["sample"])
+    assert [s[0] for s in strings] == [str(s) for s in g["strings"]]
+    # the gap class never appears in a query row
+    assert int((sample[:, 0] == 21).sum()) == 0
+
+
+def test_protein_collate_v2():
+    g = golden("protein_collate_v2")
+    tables = golden("protein_tables_k22")
+    Qb, _ = pr.uniform_tables(22, 500, "sohl-dickstein")
+    np.testing.assert_array_equal(Qb.numpy()[tables["slice_t"]], tables["Q_bar_slices"])
+    toks = T_(g["tokens"])
+    for t in (1, 37, 500):
+        src, ts, qx = pr.collate_v2(toks, t, 500, Qb, T_(g[f"expo_t{t}"]))
+        np.testing.assert_array_equal(src.numpy(), g[f"src_t{t}"])
+        np.testing.assert_array_equal(ts.numpy(), g[f"timesteps_t{t}"])
+        np.testing.assert_array_equal(qx.numpy(), g[f"q_t{t}"])
+    assert g["timesteps_t500"].tolist() == [500, 499, 499, 499]      # the reference's decrement after the first
+
+
+def _mutant_fixture():
+    g = golden("protein_mutant_scores")
+    rows = g["expo_rows"].tolist()
+    L = len([c for c in str(g["focus_seq"]) if c == c.upper()])
+    flat, Em, o = g["expo"], [], 0
+    for r in rows:
+        Em.append(torch.from_numpy(flat[o:o + r * L * 22].reshape(r, L, 22)))
+        o += r * L * 22
+    return g, Em
+
+
+def test_protein_mutant_scores(tmp_path):
+    g, Em = _mutant_fixture()
+    focus = str(g["focus_seq"])
+    start = int(str(g["focus_name"]).split("/")[-1].split("-")[0])
+    # sequences as the reference assembles them (utils.py:107-150), restated for the fixture's CSV
+    trimmed = [c for c in focus if c == c.upper()]
+    col = {start + i: k for k, i in enumerate(i for i, c in enumerate(focus) if c == c.upper())}
+    seqs, desc = ["".join(trimmed)], []
+    for line in str(g["csv"]).splitlines()[1:]:
+        muts = line.split(",")[0].split(":")
+        if all(int(m[1:-1]) in col and focus[int(m[1:-1]) - start] == m[0] and m[0] != m[-1] for m in muts):
+            s = list(trimmed)
+            for m in muts:
+                s[col[int(m[1:-1])]] = m[-1]
+            seqs.append("".join(s)); desc.append(":".join(muts))
+    assert desc == [str(d) for d in g["descriptors"]]
+    toks = torch.from_numpy(np.stack([pr.tokenize(s) for s in seqs]))
+    emb, tvec = T_(g["emb"]), T_(g["tvec"])
+    model = lambda x, tt: emb[x] + tvec[tt][:, None, :]
+    n_iter, mb, steps = int(g["n_iter"]), int(g["minibatch"]), int(g["steps"])
+    nb = (len(seqs) + mb - 1) // mb
+    tmid = g["t_mid"].tolist()
+    delta = pr.mutant_scores(toks, model, T_(g["Q_t"]), T_(g["Q_bar"]), steps, n_iter, mb,
+                             lambda i: g["orders"][i], lambda i, j: tmid[i * nb + j // mb],
+                             lambda i, j, h: Em[(i * nb + j // mb) * 3 + h])
+    np.testing.assert_allclose(delta, g["delta_elbos"], rtol=1e-6, atol=1e-7)

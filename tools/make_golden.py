@@ -13,6 +13,9 @@ is copied.  The GPU box never runs this script and never sees the reference.
 from __future__ import annotations
 
 import argparse
+import contextlib
+import io
+import tempfile
 import hashlib
 import os
 import subprocess
@@ -305,6 +308,103 @@ def part_protein():
                       for _ in range(T - 1)])
     save("protein_generate", Q_bar=Qb20.numpy(), Q_t=Qt20.numpy(), emb=emb.numpy(), tvec=tvec.numpy(),
          x_init=x_init.numpy(), expo=Es.numpy(), sample=sample.numpy(), strings=np.array(strings))
+
+
+    # --- MSA reverse sampling (no query pinning: the query comes from a data file) ------
+    Tm, Bs, Ds, Ls = 12, 2, 3, 16
+    Qb12, Qt12 = tok.q_uniform_schedule(num_steps=Tm, schedule="sohl-dickstein")
+
+    class ToyMSA(torch.nn.Module):
+        def forward(self, x, tt):
+            return emb[x] + tvec[tt][:, None, None, :]
+
+    penalty = 0.75
+    torch.manual_seed(501)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sample_m, strings_m = pg.generate_msa_d3pm(ToyMSA(), Bs, Ds, Ls, "cpu", timesteps=Tm, penalty_value=penalty,
+                                                   Q_bar=Qb12, Q=Qt12, tokenizer=tok, start_query=False)
+    torch.manual_seed(501)
+    x_init_m = torch.randint(0, K, (Bs, Ds, Ls))
+    Ea, Eq = [], []
+    for _ in range(Tm - 1):
+        ea, eq = [], []
+        for _ in range(Bs):
+            ea.append(torch.empty(Ds * Ls, K, dtype=torch.float64).exponential_(1))
+            eq.append(torch.empty(Ls, K - 1, dtype=torch.float64).exponential_(1))
+        Ea.append(torch.stack(ea)); Eq.append(torch.stack(eq))
+    save("protein_generate_msa", Q_bar=Qb12.numpy(), Q_t=Qt12.numpy(), emb=emb.numpy(), tvec=tvec.numpy(),
+         x_init=x_init_m.numpy(), expo_all=torch.stack(Ea).numpy(), expo_query=torch.stack(Eq).numpy(),
+         penalty=np.array(penalty), sample=sample_m.numpy(), strings=np.array([s[0] for s in strings_m]))
+
+    # --- CollaterV2 (utils.py:240-293) with its draws recorded -----------------------------
+    seqs = [tok.untokenize(r) for r in fasta_tokens(4)]
+    col = pu.CollaterV2(tokenizer=tok, num_steps=500, Q=Qt, Q_bar=Qb)
+    arrs = dict(tokens=fasta_tokens(4))
+    for tcase in (1, 37, 500):
+        torch.manual_seed(600 + tcase)
+        src, src_oh, tsv, tgt, tgt_oh, _, _, qx = col(seqs, tcase)
+        torch.manual_seed(600 + tcase)
+        Ec = torch.stack([torch.empty(len(seqs[0]), K, dtype=torch.float64).exponential_(1) for _ in seqs])
+        arrs.update({f"src_t{tcase}": src.numpy(), f"timesteps_t{tcase}": tsv.numpy(), f"q_t{tcase}": qx.numpy(),
+                     f"expo_t{tcase}": Ec.numpy()})
+    save("protein_collate_v2", **arrs)
+
+    # --- custom_mutant_matrix (utils.py:105-236) on a synthetic mutant list ----------------
+    Lf, Tf = 24, 30
+    Qb30, Qt30 = tok.q_uniform_schedule(num_steps=Tf, schedule="sohl-dickstein")
+    rng = np.random.RandomState(7)
+    wt = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), Lf))
+    focus_seq = wt[:5] + wt[5:8].lower() + wt[8:]               # three unmodelled (lower-case) columns
+    focus_trimmed = [c for c in focus_seq if c == c.upper()]
+    start = 24
+    lines = ["mutant,effect"]
+    cols = [i for i, c in enumerate(focus_seq) if c == c.upper()]
+    for k in range(9):
+        i = cols[int(rng.randint(len(cols)))]
+        mut = rng.choice([a for a in "ACDEFGHIKLMNPQRSTVWY" if a != focus_seq[i]])
+        m = f"{focus_seq[i]}{start + i}{mut}"
+        if k % 4 == 3:
+            i2 = cols[(cols.index(i) + 3) % len(cols)]
+            mut2 = rng.choice([a for a in "ACDEFGHIKLMNPQRSTVWY" if a != focus_seq[i2]])
+            m += f":{focus_seq[i2]}{start + i2}{mut2}"
+        lines.append(m + ",0.0")
+    lines.append(f"{focus_seq[5].upper()}{start + 5}A,0.0")       # a lower-case column: not a valid mutant
+    csv_path = os.path.join(tempfile.mkdtemp(), "mutants.csv")
+    with open(csv_path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+    class ToyT(torch.nn.Module):
+        def forward(self, x, tt):
+            return emb[x] + tvec[tt][:, None, :]
+
+    n_iter, mb = 2, 4
+    lf_eval = pl.D3PMLVBLoss(tmax=Tf, tokenizer=tok, evaluation=True)
+    np.random.seed(11); torch.manual_seed(701)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        desc, delta = pu.custom_mutant_matrix(csv_path, ToyT(), "cpu", focus_seq, f"TOY/{start}-{start + Lf - 1}",
+                                              focus_trimmed, tok, lf_eval, None, 0.0, Tf, Qt30, Qb30,
+                                              N_pred_iterations=n_iter, minibatch_size=mb)
+    # replay numpy's shuffle / randint and torch's exponential draws in call order
+    n_seq = len(desc) + 1
+    np.random.seed(11); torch.manual_seed(701)
+    orders, tmid, Em = [], [], []
+    order = np.arange(n_seq)
+    for i in range(n_iter):
+        np.random.shuffle(order)
+        orders.append(order.copy())
+        for j in range(0, n_seq, mb):
+            nb = len(order[j:j + mb])
+            for h in range(3):
+                if h == 1:
+                    tmid.append(np.random.randint(2, Tf))
+                Em.append(torch.stack([torch.empty(len(focus_trimmed), K, dtype=torch.float64).exponential_(1)
+                                       for _ in range(nb)]).numpy())
+    save("protein_mutant_scores", csv=np.array("\n".join(lines) + "\n"), focus_seq=np.array(focus_seq),
+         focus_name=np.array(f"TOY/{start}-{start + Lf - 1}"), steps=np.array(Tf), n_iter=np.array(n_iter),
+         minibatch=np.array(mb), Q_bar=Qb30.numpy(), Q_t=Qt30.numpy(), emb=emb.numpy(), tvec=tvec.numpy(),
+         descriptors=np.array(desc), delta_elbos=np.asarray(delta), orders=np.stack(orders), t_mid=np.array(tmid),
+         expo=np.array(Em, dtype=object) if False else np.concatenate([e.reshape(-1) for e in Em]),
+         expo_rows=np.array([e.shape[0] for e in Em]))
 
 
 def main():
