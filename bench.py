@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (reverse sampling, K=256 image configuration); for counter passes")
     args = ap.parse_args()
 
     import torch
@@ -182,59 +184,63 @@ def main():
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / args.steps
 
-    # ---- secondary: reverse sampling, path only (frozen logits), 10k BLAT-length sequences sharded
-    n_local = (10000 + world - 1) // world
-    sub = min(1024, n_local)
-    tok = d3pm_amd.Tokenizer()
-    Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
-    ptab = protein_tables(Qt, Qb)
-    frozen = torch.randn(sub, 263, 22, device=dev)
-    xs = torch.randint(0, 22, (sub, 263), device=dev)
-    tsteps = [torch.full((sub,), t, dtype=torch.long, device=dev) for t in range(499, 0, -1)]
-    for tt in tsteps[:20]:
-        xs = reverse_step(ptab, frozen, xs, tt)
-    torch.cuda.synchronize()
-    r0 = time.perf_counter()
-    done = 0
-    while done < n_local:
+    done = done_e2e = 0
+    rev_el = e2e_el = 1.0
+    sub = 0
+    if not args.no_secondary:
+        # ---- secondary: reverse sampling, path only (frozen logits), 10k BLAT-length sequences sharded
+        n_local = (10000 + world - 1) // world
+        sub = min(1024, n_local)
+        tok = d3pm_amd.Tokenizer()
+        Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
+        ptab = protein_tables(Qt, Qb)
+        frozen = torch.randn(sub, 263, 22, device=dev)
         xs = torch.randint(0, 22, (sub, 263), device=dev)
-        for tt in tsteps:
+        tsteps = [torch.full((sub,), t, dtype=torch.long, device=dev) for t in range(499, 0, -1)]
+        for tt in tsteps[:20]:
             xs = reverse_step(ptab, frozen, xs, tt)
-        done += sub
-    torch.cuda.synchronize()
-    rev_el = time.perf_counter() - r0
-    if world > 1:
-        el = torch.tensor([rev_el], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        rev_el = float(el.item())
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        done = 0
+        while done < n_local:
+            xs = torch.randint(0, 22, (sub, 263), device=dev)
+            for tt in tsteps:
+                xs = reverse_step(ptab, frozen, xs, tt)
+            done += sub
+        torch.cuda.synchronize()
+        rev_el = time.perf_counter() - r0
+        if world > 1:
+            el = torch.tensor([rev_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            rev_el = float(el.item())
 
-    # ---- the same loop end to end with a tiny denoiser (embedding + time embedding + linear head)
-    emb = torch.randn(22, 64, device=dev) * 0.5
-    tvec = torch.randn(501, 64, device=dev) * 0.1
-    head = torch.randn(64, 24, device=dev) * 0.3
-    tiny = lambda x, tt: (emb[x] + tvec[tt][:, None, :]) @ head
-    xs = torch.randint(0, 22, (sub, 263), device=dev)
-    for tt in tsteps[:20]:
-        xs = reverse_step(ptab, tiny(xs, tt), xs, tt)
-    torch.cuda.synchronize()
-    r0 = time.perf_counter()
-    done_e2e = 0
-    while done_e2e < n_local:
+        # ---- the same loop end to end with a tiny denoiser (embedding + time embedding + linear head)
+        emb = torch.randn(22, 64, device=dev) * 0.5
+        tvec = torch.randn(501, 64, device=dev) * 0.1
+        head = torch.randn(64, 24, device=dev) * 0.3
+        tiny = lambda x, tt: (emb[x] + tvec[tt][:, None, :]) @ head
         xs = torch.randint(0, 22, (sub, 263), device=dev)
-        for tt in tsteps:
+        for tt in tsteps[:20]:
             xs = reverse_step(ptab, tiny(xs, tt), xs, tt)
-        done_e2e += sub
-    torch.cuda.synchronize()
-    e2e_el = time.perf_counter() - r0
-    if world > 1:
-        el = torch.tensor([e2e_el], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        e2e_el = float(el.item())
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        done_e2e = 0
+        while done_e2e < n_local:
+            xs = torch.randint(0, 22, (sub, 263), device=dev)
+            for tt in tsteps:
+                xs = reverse_step(ptab, tiny(xs, tt), xs, tt)
+            done_e2e += sub
+        torch.cuda.synchronize()
+        e2e_el = time.perf_counter() - r0
+        if world > 1:
+            el = torch.tensor([e2e_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            e2e_el = float(el.item())
 
     # ---- secondary: the image configuration (B=128, 32x32x1, K=256, T=1000, Gaussian Q): dense contraction on
     # the matrix cores, fused loss fwd+bwd; priced against the dense float32 MFMA peak
     dense = None
-    if rank == 0:
+    if rank == 0 and not args.no_secondary:
         KI, TI, BI, LI = 256, 1000, 128, 1024
         di = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(1e-4, 0.02, TI, "linear"),
                                         transition_mat_type="gaussian", num_bits=8, transition_bands=None,
@@ -284,7 +290,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN},
-            "reverse_sample": {"value": done * world / rev_el, "unit": "seqs/s",
+            "reverse_sample": None if args.no_secondary else {"value": done * world / rev_el, "unit": "seqs/s",
                                "what": "full T=500 (499 steps) reverse sampling, L=263, K=22, 10000 sequences sharded "
                                        f"over {world} GPU(s) in sub-batches of {sub}, path only (frozen logits)",
                                "end_to_end_tiny_denoiser": done_e2e * world / e2e_el},
