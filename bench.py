@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--compat", action="store_true",
+                    help="time training_losses(...).mean().backward() instead of the two-launch training_step")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (reverse sampling, K=256 image configuration); for counter passes")
@@ -123,18 +125,29 @@ def main():
 
     from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
 
-    if args.no_graph:
-        def step():
-            t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
-            x_t = d.q_sample(x0, t)                               # Philox noise on device
-            losses = d._fused(logits, x0, x_t, t, "hybrid")      # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
-            logits.grad = None
-            losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
-    else:
-        # the same calls captured into one HIP graph (timestep draw, q_sample with a device-side
-        # Philox counter, fused loss, .mean(), backward) and replayed
-        graphed = d3pm_amd.graphs.GraphedTrainingLosses(d, model_fn, x0, seed=1234 + rank, params=[logits])
-        step = graphed.replay
+    # Default: DiscreteDiffusion.training_step -- timestep draw + q_sample (one launch, device Philox), fused loss
+    # with batch mean and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
+    # --compat: the reference-shaped calls, training_losses(...).mean().backward(), which add the caller's
+    # reduction and its backward (four more short launches on [B] tensors).
+    def make_step(compat, graph):
+        if compat and not graph:
+            def step():
+                t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+                x_t = d.q_sample(x0, t)                               # Philox noise on device
+                losses = d._fused(logits, x0, x_t, t, "hybrid")      # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
+                logits.grad = None
+                losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
+            return step
+        if compat:
+            return d3pm_amd.graphs.GraphedTrainingLosses(d, model_fn, x0, seed=1234 + rank, params=[logits]).replay
+        if not graph:
+            def step():
+                logits.grad = None
+                d.training_step(model_fn, x_start=x0)
+            return step
+        return d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=1234 + rank, params=[logits]).replay
+
+    step = make_step(args.compat, not args.no_graph)
 
     for _ in range(args.warmup):
         step()
@@ -156,6 +169,18 @@ def main():
         elapsed = float(el.item())
     tokens = B * L * args.steps * world
 
+    other_ms = None
+    if not args.no_secondary:       # the other call shape, for the record (same graph/eager mode, 100 steps)
+        other = make_step(not args.compat, not args.no_graph)
+        for _ in range(10):
+            other()
+        torch.cuda.synchronize()
+        o0 = time.perf_counter()
+        for _ in range(100):
+            other()
+        torch.cuda.synchronize()
+        other_ms = (time.perf_counter() - o0) * 10.0
+
     # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the
     # stream, HIP events at both ends; rocprofv3 --kernel-trace of this command reports the same
     # kernel's average duration (profiles/).
@@ -170,7 +195,7 @@ def main():
 
     def fused_only():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_s), K, ptr(x0), 8, ptr(xt_s), 8, ptr(t_s), 4, B, L,
-                                   LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_s), ptr(ws),
+                                   LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_s), None, None, 0, ptr(ws),
                                    wsb, sp))
 
     for _ in range(10):
@@ -258,7 +283,7 @@ def main():
 
         def dense_only():
             check(lib.d3pm_hybrid_loss(tbi.desc(), ptr(lgi), KI, ptr(x0i), 8, ptr(xti), 8, ptr(ti), 4, BI, LI,
-                                       LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dli), ptr(wsi),
+                                       LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dli), None, None, 0, ptr(wsi),
                                        wsbi, sp))
         for _ in range(3):
             dense_only()
@@ -282,10 +307,13 @@ def main():
             "metric": METRIC, "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic protein D3PM B={B} L={L} K={K} T={T} {args.kind} Q, per GPU: q_sample "
-                                   "(Philox) + fused posterior/hybrid-loss fwd+bwd to dlogits, denoiser excluded",
+            "config": {"workload": f"synthetic protein D3PM B={B} L={L} K={K} T={T} {args.kind} Q, per GPU: timestep draw + "
+                                   "q_sample (Philox) + fused posterior/hybrid-loss fwd+bwd to dlogits with batch mean, "
+                                   "denoiser excluded",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective",
-                       "launch": "eager" if args.no_graph else "hip-graph replay"},
+                       "launch": "eager" if args.no_graph else "hip-graph replay",
+                       "calls": "training_losses(...).mean().backward()" if args.compat else "training_step(...)",
+                       "other_call_shape_ms_per_step": other_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",

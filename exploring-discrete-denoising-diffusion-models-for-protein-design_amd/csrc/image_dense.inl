@@ -270,6 +270,7 @@ enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
 
 struct DenseExtra {
   int B;
+  unsigned long long* rng_counter; unsigned long long rng_step;   // see LossOut
   const float* logits; long ld;
   // loss
   int loss_type; float hybrid_coeff; float grad_scale; const float* grad_out; float* part; float* dlogits;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   // Workgroups are dealt to the 8 XCDs round-robin by index; all chunks of a batch
   // element go to the same XCD so that its two 256 KB matrices (one timestep) are
   // fetched into one L2 only.  The grid is B rounded up to a multiple of 8.
+  if (blockIdx.x == 0 && threadIdx.x == 0 && e.rng_counter) *e.rng_counter += e.rng_step;
   const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
   const int b = (within / a.chunks) * 8 + xcd, chunk = within % a.chunks;
   if (b >= e.B) return;
@@ -670,8 +672,8 @@ static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start
 
 static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
                              const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos, int loss_type,
-                             float hybrid_coeff, float grad_scale, const float* grad_out, float* vb, float* ce,
-                             float* loss, float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                             float hybrid_coeff, float grad_scale, const float* grad_out, LossOut o,
+                             float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
   D3PM_CHECK_ARG(!dlogits || tb->qbarT, "dense backward needs the transposed cumulative table (qbarT)");
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits)) && aligned16(tb->qbar) &&
                    aligned16(tb->qoneT);
@@ -686,10 +688,13 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       DenseExtra e{};
       e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
       e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
+      e.rng_counter = o.rng_counter; e.rng_step = o.rng_step;
       const int rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s)
                              : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{vb, ce, loss, e.part}, B,
+      LossOut oo = o;
+      oo.part = e.part;
+      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, oo, B,
                          a.chunks, npos, loss_type, hybrid_coeff, 1.0f / LN2);
       D3PM_LAUNCH_CHECK("k_loss_finalize");
       return D3PM_OK;
@@ -729,7 +734,8 @@ static int dense_prior(const d3pm_tables_f32* tb, const void* x0, int tok_bytes,
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_dense_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_dense_prior");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{out, nullptr, nullptr, part}, B,
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s,
+                       LossOut{out, nullptr, nullptr, part, nullptr, 0}, B,
                        a.chunks, npos, D3PM_LOSS_KL, 0.0f, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;

@@ -109,16 +109,30 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
 // uniform per token suffices: inverse CDF over the prefix sums of (off + eps),
 // kept in LDS per workgroup (one timestep), with the x0 entry spliced in.  One
 // thread per token, 16 bytes of traffic per token.
+// With `t_draw` the timestep of each batch element is drawn here as well,
+// uniform on [0, T) from the same Philox key (counter 2^63 + b, disjoint from the
+// token counters), and written to t_draw[b] for the denoiser and the loss.
+__device__ __forceinline__ int draw_timestep(int b, int T, uint64_t offset, uint64_t seed) {
+  const U4 r = philox4x32_10((1ull << 63) + (uint64_t)b, offset, seed);
+  return (int)(((uint64_t)r.x * (uint64_t)T) >> 32);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t seed, uint64_t offset,
                                                          const uint64_t* __restrict__ offset_dev,
-                                                         int64_t* __restrict__ out) {
+                                                         int32_t* __restrict__ t_draw, int64_t* __restrict__ out) {
   __shared__ float cdf[257];     // cdf[j] = sum_{i<j} (off_i + eps)
   __shared__ float dmo[256];     // diag_j - off_j
   const int K = a.tb.K;
   const float eps = a.tb.eps;
   if (offset_dev) offset += *offset_dev;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  int t;
+  if (t_draw) {
+    t = draw_timestep(b, a.tb.T, offset, seed);
+    if (chunk == 0 && threadIdx.x == 0) t_draw[b] = t;
+  } else {
+    t = load_tok(a.t, b, a.t_bytes);
+  }
   const float* dgd_ = dg(a.tb.qbar_digest, t, 0, K);
   const float* dgo_ = dg(a.tb.qbar_digest, t, 1, K);
   if (threadIdx.x < 64) {        // one wave scans K <= 256 weights, four per lane
@@ -293,7 +307,26 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 struct LossOut {
   float* vb; float* ce; float* loss;   // [B], any may be null (chunks == 1)
   float* part;                         // [B][chunks][2] (chunks > 1)
+  // the caller's Philox counter, advanced by the first workgroup of the loss kernel:
+  // every reader of the old value (the corruption kernel) finished before this
+  // launch began, the next reader starts after it ends
+  unsigned long long* rng_counter; unsigned long long rng_step;
 };
+
+// Optional tail of the loss step, a single small workgroup launched behind the loss
+// kernel(s): the mean of loss[0..B) summed in a fixed order.  (Folding this into
+// the last workgroup of the loss kernel needs device-scope release fences, which
+// on a multi-XCD part write back the whole L2 and cost more than this launch:
+// measured 18.8 us against 10.5 + 2.5 us.)
+__global__ __launch_bounds__(256) void k_batch_mean(const float* __restrict__ loss, int B, float* __restrict__ mean) {
+  __shared__ float red[4];
+  float acc = 0;
+  for (int i = threadIdx.x; i < B; i += 256) acc += loss[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *mean = (((red[0] + red[1]) + red[2]) + red[3]) / (float)B;
+}
 
 __device__ __forceinline__ void write_losses(const LossOut& o, int b, float svb, float sce, long npos, int loss_type,
                                              float hybrid_coeff) {
@@ -358,6 +391,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
   // Start-up order: the timestep (a scalar load), then the few digest rows that
   // depend on it, then the first rows of logits; vector loads return in issue
   // order, so the digests must not queue behind the row burst.
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
   D3PM_TL_DECL;
   D3PM_TL(0);
   const int t = load_tok(a.t, b, a.t_bytes);
@@ -559,6 +593,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
       out.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
     }
   }
+
   D3PM_TL(8);
   D3PM_TL_FLUSH;
 }
@@ -769,7 +804,8 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
     return dense_q_sample(tb, x0, tok_bytes, t, t_bytes, B, npos, noise, noise_kind, seed, offset, offset_dev, x_t, s);
   if (noise_kind == D3PM_NOISE_PHILOX) {
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, 1);    // one thread per token
-    hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev, x_t);
+    hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev,
+                       (int32_t*)nullptr, x_t);
     D3PM_LAUNCH_CHECK("k_q_sample_icdf");
     return D3PM_OK;
   }
@@ -789,6 +825,36 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
     D3PM_LAUNCH_CHECK("k_q_sample");
     return D3PM_OK;
   });
+}
+
+__global__ void k_draw_t(int B, int T, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                         int32_t* __restrict__ t_draw) {
+  if (offset_dev) offset += *offset_dev;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) t_draw[b] = draw_timestep(b, T, offset, seed);
+}
+
+extern "C" int d3pm_q_sample_draw_t(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
+                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* t_out,
+                                    int64_t* x_t, void* stream) {
+  if (int rc = check_common(tb, B, npos)) return rc;
+  D3PM_CHECK_ARG(bytes_ok(tok_bytes), "token width must be 4 or 8 bytes");
+  if (B == 0) return D3PM_OK;
+  D3PM_CHECK_ARG(t_out, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (npos == 0 || !tb->structured) {
+    hipLaunchKernelGGL(k_draw_t, dim3((B + 255) / 256), dim3(256), 0, s, B, tb->T, seed, offset, offset_dev, t_out);
+    D3PM_LAUNCH_CHECK("k_draw_t");
+    if (npos == 0) return D3PM_OK;
+    D3PM_CHECK_ARG(x0 && x_t, "null pointer");
+    return dense_q_sample(tb, x0, tok_bytes, t_out, 4, B, npos, nullptr, D3PM_NOISE_PHILOX, seed, offset, offset_dev, x_t,
+                          s);
+  }
+  D3PM_CHECK_ARG(x0 && x_t, "null pointer");
+  ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, nullptr, 4, B, npos, 1);    // one thread per token
+  hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev, t_out, x_t);
+  D3PM_LAUNCH_CHECK("k_q_sample_icdf");
+  return D3PM_OK;
 }
 
 extern "C" int d3pm_q_posterior_logits(const d3pm_tables_f32* tb, const void* x_start, int x_start_is_logits, long ld,
@@ -826,11 +892,16 @@ extern "C" size_t d3pm_hybrid_loss_workspace(int B, long npos, int K) {
   return (size_t)(B > 0 ? B : 1) * (size_t)chunks * 2 * sizeof(float);
 }
 
+static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
+                                  const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
+                                  int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, LossOut o,
+                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
                                 const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
                                 int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, float* vb,
-                                float* ce, float* loss, float* dlogits, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+                                float* ce, float* loss, float* dlogits, float* loss_mean, uint64_t* rng_counter,
+                                uint64_t rng_step, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_common(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(bytes_ok(tok_bytes) && bytes_ok(xt_bytes) && bytes_ok(t_bytes),
                  "token/timestep width must be 4 or 8 bytes");
@@ -844,9 +915,30 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
   D3PM_CHECK_ARG(npos * ld < 0x3fffffffL, "one batch element spans %ld logits: more than 2^30", npos * ld);
   D3PM_CHECK_ARG(logits && x0 && x_t && t, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (!tb->structured)
-    return dense_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type, hybrid_coeff,
-                             grad_scale, grad_out, vb, ce, loss, dlogits, workspace, workspace_bytes, s);
+  D3PM_CHECK_ARG(!loss_mean || loss, "the batch mean needs the per-sample loss output");
+  LossOut o{vb, ce, loss, nullptr, (unsigned long long*)rng_counter, (unsigned long long)rng_step};
+  int rc;
+  if (!tb->structured) {
+    rc = dense_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type, hybrid_coeff,
+                           grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
+  } else {
+    rc = structured_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
+                                hybrid_coeff, grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
+  }
+  if (rc) return rc;
+  if (loss_mean) {
+    hipLaunchKernelGGL(k_batch_mean, dim3(1), dim3(256), 0, s, loss, B, loss_mean);
+    D3PM_LAUNCH_CHECK("k_batch_mean");
+  }
+  return D3PM_OK;
+}
+
+static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
+                                  const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
+                                  int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, LossOut o,
+                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  float* partials = (float*)workspace;
+  const size_t partial_bytes = workspace_bytes;
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits));
   return dispatch_layout_wide(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
@@ -869,12 +961,10 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }
-    LossOut o{vb, ce, loss, nullptr};
     if (a.chunks > 1) {
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes,
-                     need);
-      o.part = (float*)workspace;
+      D3PM_CHECK_ARG(partials && partial_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      o.part = partials;
     }
     const dim3 grid(B * a.chunks), blk(block);
     if (dlogits)
@@ -961,7 +1051,8 @@ extern "C" int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_prior");
-    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, LossOut{out, nullptr, nullptr, part}, B,
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s,
+                       LossOut{out, nullptr, nullptr, part, nullptr, 0}, B,
                        a.chunks, npos, D3PM_LOSS_KL, 0.0f, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;

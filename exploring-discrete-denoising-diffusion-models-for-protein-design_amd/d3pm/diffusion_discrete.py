@@ -77,7 +77,7 @@ class _FusedLoss(torch.autograd.Function):
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=lg.device)
         check(lib.d3pm_hybrid_loss(tables.desc(), ptr(lg), K, ptr(x0), tok_bytes(x0), ptr(x_t), tok_bytes(x_t),
                                    ptr(t), tok_bytes(t), B, npos, loss_type, float(lam), float(baked), None,
-                                   None, None, ptr(loss), ptr(dl), ptr(ws), ws_bytes, stream_ptr()))
+                                   None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), ws_bytes, stream_ptr()))
         ctx.dl, ctx.baked, ctx.shape, ctx.dtype = dl, float(baked), logits.shape, logits.dtype
         return loss
 
@@ -96,6 +96,21 @@ class _FusedLoss(torch.autograd.Function):
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)
         return out, None, None, None, None, None, None, None
+
+
+class _Handoff(torch.autograd.Function):
+    """Feeds a gradient that already exists into autograd: the node's backward
+    returns the buffer it was given and drops its own reference, so that a leaf
+    can adopt the buffer instead of copying it."""
+
+    @staticmethod
+    def forward(ctx, pred, holder):
+        ctx.holder = holder
+        return torch.empty((), dtype=torch.float32, device=pred.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.holder.pop(), None
 
 
 class DiscreteDiffusion:
@@ -391,6 +406,72 @@ class DiscreteDiffusion:
         losses = self._fused(pred, x_start, x_t, t, self.loss_type)
         assert losses.shape == t.shape
         return losses
+
+    def training_step(self, model_fn, *, x_start, rng=None, backward=True):
+        """One training step of the path in two launches around the denoiser.
+
+        The reference's step is ``training_losses(...)`` (:545-582) followed by the
+        caller's ``.mean().backward()``.  Here the timestep draw and the forward
+        corruption are one kernel, and the fused loss kernel also produces the
+        batch mean and d mean / d logits, which is handed straight to
+        ``torch.autograd.backward(logits, dlogits)`` -- no reduction, fill, divide or
+        rescale launches in between.  Noise and timesteps come from the device
+        Philox stream: ``rng=(seed, counter)`` with ``counter`` a one-element int64
+        device tensor (advanced by the loss kernel itself, for HIP-graph replay),
+        or torch's CUDA generator when ``rng`` is None.
+
+        Returns a dict: ``loss`` (scalar float32 tensor, mean over the batch),
+        ``losses`` [B], ``t`` [B] int32, ``x_t``; gradients are accumulated into
+        whatever the logits depend on when ``backward`` is true."""
+        if self.loss_type not in _lib.LOSS:
+            raise NotImplementedError(self.loss_type)
+        if self.model_prediction != "x_start":
+            raise NotImplementedError(self.model_prediction)
+        x0 = _as_tokens(x_start)
+        _lib.require_device(x0)
+        tb = self.tables()
+        B, npos = self._dims(x0)
+        dev = x0.device
+        seed = off = 0
+        counter = None
+        if rng is not None:
+            seed, counter = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, rng[1]
+            assert counter.dtype == torch.int64 and counter.is_cuda and counter.numel() == 1
+        else:
+            seed, off = _philox_ticket(dev)
+        t = torch.empty(B, dtype=torch.int32, device=dev)
+        x_t = torch.empty(x0.shape, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(t),
+                                           ptr(x_t), stream_ptr()))
+        pred = self._denoiser_logits(model_fn, x_t, t)
+        assert pred.shape == x0.shape + (tb.K,), pred.shape
+        lg = pred.detach().contiguous()
+        if lg.dtype != torch.float32:
+            lg = lg.float()
+        want_grad = backward and pred.requires_grad
+        losses = torch.empty(B, dtype=torch.float32, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev)
+        dl = torch.empty_like(lg) if want_grad else None
+        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
+                                       _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0),
+                                       float(np.float32(1.0) / np.float32(max(B, 1))), None, None, None, ptr(losses),
+                                       ptr(dl), ptr(mean), ptr(counter), 4 if counter is not None else 0, ptr(ws),
+                                       ws_bytes, stream_ptr()))
+        if want_grad:
+            holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
+            del dl
+            torch.autograd.backward(_Handoff.apply(pred, holder), self._unit(dev))
+        return {"loss": mean, "losses": losses, "t": t, "x_t": x_t}
+
+    def _unit(self, dev):
+        one = getattr(self, "_one", None)
+        if one is None or one.device != dev:
+            one = self._one = torch.ones((), dtype=torch.float32, device=dev)
+        return one
 
     @torch.no_grad()
     def calc_bpd_loop(self, model_fn, *, x_start):

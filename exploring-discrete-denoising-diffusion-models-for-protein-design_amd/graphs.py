@@ -57,3 +57,38 @@ class GraphedTrainingLosses:
         """One step; returns the (static) scalar loss tensor."""
         self.graph.replay()
         return self.loss
+
+
+class GraphedTrainingStep:
+    """``DiscreteDiffusion.training_step(model_fn, x_start=...)`` -- timestep draw +
+    corruption, the denoiser, the fused loss with batch mean and gradient, and the
+    backward through the denoiser -- captured once and replayed.  The Philox
+    counter lives on the device and is advanced by the loss kernel, so the graph
+    holds no bookkeeping launches at all.  Arguments as for
+    ``GraphedTrainingLosses``; ``replay()`` returns the static result dict."""
+
+    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0, warmup: int = 3, params=()):
+        self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
+        self.seed = int(seed)
+        dev = x_start.device
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        diffusion.tables()
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for p in params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+
+    def _body(self):
+        return self.diffusion.training_step(self.model_fn, x_start=self.x_start, rng=(self.seed, self.counter))
+
+    def replay(self):
+        self.graph.replay()
+        return self.out

@@ -133,6 +133,14 @@ int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, cons
                   int B, long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
                   const uint64_t* offset_dev, int64_t* x_t, void* stream);
 
+/* The first two lines of training_losses (:549-556) with on-device noise: t_b
+ * uniform on [0, T) for every batch element (t_out int32 [B], the reference
+ * draws torch.randint) and x_t = q_sample(x0, t), one launch for column-
+ * structured tables.  Philox stream as for d3pm_q_sample. */
+int d3pm_q_sample_draw_t(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
+                         uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* t_out,
+                         int64_t* x_t, void* stream);
+
 /* q_posterior_logits (:312-336).  x_start_is_logits == 0: x_start is a token
  * array; != 0: float32 logits [B,npos,ld].  out float32 [B,npos,K].  With
  * x_start_is_logits this is also p_logits (:339-381) for model_output='logits',
@@ -152,11 +160,18 @@ size_t d3pm_hybrid_loss_workspace(int B, long npos, int K);
  *   grad_out float32 [B] upstream gradient per sample, or NULL for all ones
  *   vb, ce, loss  float32 [B] (any may be NULL)
  *   dlogits float32 [B,npos,ld] or NULL (forward only); columns >= K get 0
+ *   loss_mean (may be NULL): float32 scalar, mean of loss[0..B) summed in a
+ *     fixed order -- the `.mean()` of the training loop (:582 returns [B]; the
+ *     notebook reduces it); one single-workgroup launch behind the loss kernel
+ *   rng_counter (may be NULL): *rng_counter += rng_step, done by the loss kernel;
+ *     the device-side Philox counter of d3pm_q_sample(_draw_t), so that a
+ *     captured HIP graph needs no separate increment
  *   workspace: d3pm_hybrid_loss_workspace() bytes, contents irrelevant. */
 int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld,
                      const void* x0, int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
                      int B, long npos, int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out,
                      float* vb, float* ce, float* loss, float* dlogits,
+                     float* loss_mean, uint64_t* rng_counter, uint64_t rng_step,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* In-place per-sample rescale g[b,:] *= upstream[b]/baked; blocks whose

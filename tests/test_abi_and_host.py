@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, n), f"{n} declared in include/d3pm_hip.h but not exported"
     # and the binding lists exactly the header's functions
     assert sorted(pkg._lib.SIGNATURES) == names
-    assert pkg._lib.lib.d3pm_abi_version() == 2
+    assert pkg._lib.lib.d3pm_abi_version() == 3
 
 
 def test_struct_layout_matches_header(pkg):
@@ -99,7 +99,7 @@ def test_c_abi_argument_checks_without_gpu(pkg):
     assert rc == L.EINVAL
     tb = L.TablesF32(32, 5, 1, 1e-6, 1, 1, None, None, None)
     rc = L.lib.d3pm_hybrid_loss(ctypes.byref(tb), 1, 32, 1, 8, 1, 8, 1, 8, 2, 4, 9, 0.0, 1.0, None, None, None, None,
-                                None, None, 0, None)
+                                None, None, None, 0, None, 0, None)
     assert rc == L.EUNSUPPORTED
     with pytest.raises(NotImplementedError):
         L.check(rc)

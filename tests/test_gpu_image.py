@@ -42,7 +42,7 @@ def make(pkg, g, kind, bits, bands=None, lam=0.001, loss_type="hybrid"):
 
 
 def close(a, b, rtol=RTOL, atol=1e-6, what=""):
-    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    a, b = (x.detach().cpu().numpy() if torch.is_tensor(x) else x for x in (a, b))
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
 
 
@@ -279,3 +279,73 @@ def test_q_sample_device_noise_distribution(pkg):
             q /= q.sum()
             tol = 5 * np.sqrt(q * (1 - q) / n) + 2e-6
             assert (np.abs(freq - q) < tol).all(), (kind, tval, freq, q)
+
+
+@pytest.mark.parametrize("kind,bits,B,L", [("uniform", 5, 256, 96), ("uniform", 5, 6, 700), ("absorbing", 4, 200, 33),
+                                            ("gaussian", 4, 5, 40)])
+def test_training_step_matches_separate_calls(pkg, kind, bits, B, L):
+    """The two-launch step (timestep draw + corruption; loss + batch mean + gradient) against the
+    reference-shaped calls on the timesteps and noisy tokens it produced."""
+    K, T = 2 ** bits, 50
+    betas = pkg.generate_betas(1e-4, 0.02, T, "linear") if kind == "gaussian" else pkg.generate_betas(0.0, 0.0, T, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid", hybrid_coeff=0.01,
+                              device=DEV)
+    gen = torch.Generator().manual_seed(B + L)
+    x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen).to(DEV)
+    logits = (torch.randn(B, L, 1, 1, K, generator=gen) * 2).to(DEV).requires_grad_(True)
+    counter = torch.full((1,), 40, dtype=torch.int64, device=DEV)
+    seen = {}
+
+    def model_fn(x, t):
+        seen["x"], seen["t"] = x, t
+        return logits * 1.0                       # a non-leaf, so the gradient flows through autograd
+
+    out = d.training_step(model_fn, x_start=x0, rng=(123, counter))
+    assert int(counter.item()) == 44              # advanced by the loss kernel
+    t, x_t = out["t"], out["x_t"]
+    assert t.dtype == torch.int32 and t.shape == (B,) and int(t.min()) >= 0 and int(t.max()) < T
+    assert seen["x"] is x_t and seen["t"] is t
+    # the same Philox stream through q_sample gives the same corruption
+    c2 = torch.full((1,), 40, dtype=torch.int64, device=DEV)
+    assert torch.equal(d.q_sample(x0, t, rng=(123, c2)), x_t)
+    ref_logits = logits.detach().clone().requires_grad_(True)
+    ref = d._fused(ref_logits, x0, x_t, t, "hybrid")
+    ref.mean().backward()
+    assert torch.equal(out["losses"], ref)
+    close(out["loss"], ref.mean(), atol=LOSS_ATOL, what="batch mean")
+    close(logits.grad, ref_logits.grad, atol=1e-5 * float(ref_logits.grad.abs().max()), what="gradient")
+    # second step: fresh draw, the arrival counter was left clean
+    logits.grad = None
+    out2 = d.training_step(model_fn, x_start=x0, rng=(123, counter))
+    assert int(counter.item()) == 48 and not torch.equal(out2["x_t"], x_t)
+    close(out2["loss"], out2["losses"].mean(), atol=LOSS_ATOL, what="batch mean, second step")
+    # torch's generator as the source, forward only
+    torch.manual_seed(7)
+    a = d.training_step(lambda x, tt: logits.detach(), x_start=x0, backward=False)
+    torch.manual_seed(7)
+    b = d.training_step(lambda x, tt: logits.detach(), x_start=x0, backward=False)
+    assert torch.equal(a["x_t"], b["x_t"]) and torch.equal(a["t"], b["t"]) and torch.equal(a["losses"], b["losses"])
+
+
+def test_training_step_timestep_distribution_and_graph(pkg):
+    K, T, B, L = 32, 500, 4096, 8
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    x0 = torch.randint(0, K, (B, L, 1, 1), device=DEV)
+    logits = torch.randn(B, L, 1, 1, K, device=DEV, requires_grad=True)
+    g = pkg.graphs.GraphedTrainingStep(d, lambda x, tt: logits, x0, seed=5, params=[logits])
+    ts = []
+    for _ in range(8):
+        out = g.replay()
+        ts.append(out["t"].clone())
+        assert logits.grad is not None and torch.isfinite(logits.grad).all()
+    ts = torch.cat(ts).cpu().numpy()
+    assert len(set(map(bytes, np.split(ts, 8)))) == 8                  # every replay draws anew
+    counts = np.bincount(ts, minlength=T)
+    exp = len(ts) / T
+    chi2 = float(((counts - exp) ** 2 / exp).sum())
+    assert counts.min() > 0 and chi2 < T + 6 * np.sqrt(2 * T), chi2    # uniform on [0, T): chi-square within 6 sigma
+    ref = d._fused(logits.detach(), x0, out["x_t"], out["t"], "hybrid")
+    assert torch.equal(out["losses"], ref)

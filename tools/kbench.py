@@ -57,11 +57,11 @@ def main():
 
     def f_loss():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(x_t), 8, ptr(t), 4, B, L, LOSS["hybrid"],
-                                   0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), ptr(ws), wsb, s))
+                                   0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb, s))
 
     def f_loss_fwd():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(x_t), 8, ptr(t), 4, B, L, LOSS["hybrid"],
-                                   0.001, 1.0 / B, None, None, None, ptr(loss), None, ptr(ws), wsb, s))
+                                   0.001, 1.0 / B, None, None, None, ptr(loss), None, None, None, 0, ptr(ws), wsb, s))
 
     def f_qs():
         check(lib.d3pm_q_sample(tb.desc(), ptr(x0), 8, ptr(t), 4, B, L, None, NOISE_PHILOX, 1, 0, None, ptr(x_t), s))

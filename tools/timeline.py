@@ -39,7 +39,7 @@ sp = stream_ptr()
 
 def run():
     check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, LOSS["hybrid"],
-                               0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), ptr(ws), wsb, sp))
+                               0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb, sp))
 
 
 import time
@@ -48,7 +48,7 @@ if MODE == "nograd":
     dl = None
     def run():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, LOSS["hybrid"],
-                                   0.001, 1.0 / B, None, None, None, ptr(loss), None, ptr(ws), wsb, sp))
+                                   0.001, 1.0 / B, None, None, None, ptr(loss), None, None, None, 0, ptr(ws), wsb, sp))
 for _ in range(20):
     run()
 torch.cuda.synchronize()

@@ -28,7 +28,7 @@ wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
 ws = torch.empty(max(wsb // 4, 1), device=dev)
 for _ in range(3):
     check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, LOSS["hybrid"],
-                               0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), ptr(ws), wsb, stream_ptr()))
+                               0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb, stream_ptr()))
 torch.cuda.synchronize()
 raw = C.CDLL(os.environ["D3PM_LIB"])
 buf = np.zeros((256, 16, 9), dtype=np.uint64)
