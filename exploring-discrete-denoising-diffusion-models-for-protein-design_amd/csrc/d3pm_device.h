@@ -115,13 +115,31 @@ __device__ __forceinline__ int group_min(int v) {
 }
 
 // Inclusive prefix sum over the lanes of a group, in lane order (g = lane index in the group).
+// Distances below 16 stay inside a DPP row (row_shr); 16 and 32 go through the LDS crossbar.
+// (groups of up to 16 lanes never straddle a row; wider groups use the crossbar for every step)
+template <int G, int D, typename T>
+__device__ __forceinline__ T lane_up(T v) {
+  if constexpr (G > 16) return __shfl_up(v, D, 64);
+  else if constexpr (D == 1) return dpp_mov<0x111>(v);   // row_shr:1
+  else if constexpr (D == 2) return dpp_mov<0x112>(v);   // row_shr:2
+  else if constexpr (D == 4) return dpp_mov<0x114>(v);   // row_shr:4
+  else return dpp_mov<0x118>(v);                         // row_shr:8
+}
+template <int G, int D, typename T>
+__device__ __forceinline__ void scan_step(T& v, int g) {
+  if constexpr (D < G) {
+    const T up = lane_up<G, D>(v);
+    if (g >= D) v += up;
+  }
+}
 template <int G, typename T>
 __device__ __forceinline__ T group_scan_inclusive(T v, int g) {
-#pragma unroll
-  for (int d = 1; d < G; d <<= 1) {
-    const T up = __shfl_up(v, d, 64);
-    if (g >= d) v += up;
-  }
+  scan_step<G, 1>(v, g);
+  scan_step<G, 2>(v, g);
+  scan_step<G, 4>(v, g);
+  scan_step<G, 8>(v, g);
+  scan_step<G, 16>(v, g);
+  scan_step<G, 32>(v, g);
   return v;
 }
 
@@ -135,8 +153,7 @@ __device__ __forceinline__ int group_pick(const T (&w)[V], int g, T u, int fallb
 #pragma unroll
   for (int v = 0; v < V; ++v) lane_tot += w[v];
   const T incl = group_scan_inclusive<G>(lane_tot, g);
-  const int lane = threadIdx.x & 63;
-  const T total = __shfl(incl, (lane & ~(G - 1)) + (G - 1), 64);
+  const T total = group_max<G>(incl);          // weights are non-negative: the last lane's prefix is the largest
   const T target = u * total;
   T run = incl - lane_tot;
   int key = 0x7fffffff;

@@ -285,6 +285,76 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
   }
 }
 
+// The same step for on-device noise.  Nothing has to match a recorded draw, so the
+// marginal is evaluated in float32 (weights accurate to 1e-6 relative), the softmax
+// uses the hardware exp2, and the uniforms come from a per-wave pool: one Philox
+// call per lane yields 256 words per wave, parked in LDS and handed out one word
+// per token (a 32-bit uniform) over the next 256 / tokens-per-pass passes.
+template <class L>
+__global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a, const float* __restrict__ pred, long ld,
+                                                                     uint64_t seed, uint64_t offset,
+                                                                     const uint64_t* __restrict__ offset_dev,
+                                                                     float last_class_div, long exclude_last_prefix,
+                                                                     int64_t* __restrict__ out) {
+  if (offset_dev) offset += *offset_dev;
+  constexpr int WAVES = PBLOCK / 64, TPW = 64 / L::G;      // tokens per wave and pass
+  constexpr int REFILL = 256 / TPW;                         // passes served by one pool
+  __shared__ uint32_t pool[WAVES][256];
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tok_in_wave = lane / L::G;
+  const int t = (int)a.t[b];
+  float md[L::V], mo[L::V];
+#pragma unroll
+  for (int v = 0; v < L::V; ++v) {
+    const int c = L::cls(g, v);
+    md[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
+    mo[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
+  }
+  const float inv_last = 1.0f / last_class_div;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  int it = 0;
+  for (long pos0 = chunk * a.chunk_pos; pos0 < p1; pos0 += PBLOCK / L::G, ++it) {
+    if (it % REFILL == 0) {          // wave-private pool: no workgroup barrier needed, LDS ops of a wave are in order
+      const U4 r = philox4x32_10(((uint64_t)blockIdx.x << 32) + (uint64_t)(it / REFILL) * PBLOCK + threadIdx.x, offset,
+                                 seed);
+      pool[wave][lane] = r.x; pool[wave][64 + lane] = r.y; pool[wave][128 + lane] = r.z; pool[wave][192 + lane] = r.w;
+    }
+    const long pos = pos0 + slot;
+    if (pos >= p1) continue;         // whole lane groups leave together
+    const long n = (long)b * a.npos + pos;
+    const int xt = (int)a.xt[n];
+    float z[L::V];
+    load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
+    const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
+    float m = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) m = fmaxf(m, (L::cls(g, v) < K) ? z[v] : -INFINITY);
+    m = group_max<L::G>(m);
+    float p[L::V], s2 = 0;
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      p[v] = (L::cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
+      s2 = fmaf(p[v], p[v], s2);
+    }
+    s2 = group_sum<L::G>(s2);       // the softmax normaliser cancels in the draw: p stays unnormalised
+    const float a_diag = (float)dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = (float)dgd(a.tb.qone_digest, t, 1, K)[xt];
+    const bool no_last = pos < exclude_last_prefix;
+    float r[L::V];
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      const float pp = p[v] * p[v];
+      r[v] = (c < K) ? ((c == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp) : 0.0f;
+      if (c == K - 1) r[v] = no_last ? 0.0f : r[v] * inv_last;
+    }
+    const float u = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+    const int pick = group_pick<L::G, L::V>(r, g, u, xt, [](int gg, int vv) { return L::cls(gg, vv); });
+    if (g == 0) out[n] = pick;
+  }
+}
+
 static int check_prot(const d3pm_tables_f64* tb, int B, long npos) {
   D3PM_CHECK_ARG(tb && tb->qbar_digest && tb->qone_digest, "tables descriptor or digest is null");
   D3PM_CHECK_ARG(tb->K >= 2 && tb->K <= 256 && tb->T >= 1, "need 2 <= K <= 256, T >= 1 (K=%d, T=%d)", tb->K, tb->T);
@@ -362,8 +432,8 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
 
 extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,
                                      const int64_t* t, int B, long npos, const double* expo, uint64_t seed,
-                                     uint64_t offset, double last_class_div, long exclude_last_prefix, int64_t* out,
-                                     void* stream) {
+                                     uint64_t offset, const uint64_t* offset_dev, double last_class_div,
+                                     long exclude_last_prefix, int64_t* out, void* stream) {
   if (int rc = check_prot(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(ld >= tb->K, "row stride %ld smaller than K=%d", ld, tb->K);
   D3PM_CHECK_ARG(last_class_div > 0.0 && exclude_last_prefix >= 0, "last-class divisor must be positive, prefix >= 0");
@@ -372,6 +442,12 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   return dispatch_layout(tb->K, false, [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
+    if (!expo) {
+      hipLaunchKernelGGL(k_lvb_reverse_device_noise<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred,
+                         ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
+      return D3PM_OK;
+    }
     hipLaunchKernelGGL(k_lvb_reverse<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred, ld, expo,
                        seed, offset, last_class_div, exclude_last_prefix, out);
     D3PM_LAUNCH_CHECK("k_lvb_reverse");

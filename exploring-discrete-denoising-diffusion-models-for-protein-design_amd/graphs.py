@@ -92,3 +92,54 @@ class GraphedTrainingStep:
     def replay(self):
         self.graph.replay()
         return self.out
+
+
+class GraphedReverseSampler:
+    """The T-1 reverse steps of ``generate_d3pm`` (denoiser call + posterior
+    marginal + categorical draw per step) for a fixed batch shape, captured into one
+    HIP graph.  Launched step by step from Python the loop is bound by the host
+    (a few launches of a few microseconds each per step); the replay is bound by
+    the kernels.  Every replay draws fresh noise: the Philox offset of each step is
+    its capture-time offset plus a device counter that ``sample()`` advances.
+
+    ``model_fn(x [B,L] int64, t [B] int64) -> logits [B,L,n_tokens]`` must be
+    capturable.  ``sample(x_init=None)`` returns the static [B,L] result tensor
+    (clone it before the next call); x_T is drawn uniformly unless given."""
+
+    def __init__(self, tables, model_fn, batch_size: int, seq_len: int, timesteps: int, device, seed: int = 0,
+                 warmup: int = 2):
+        from .protein_generation.generate import reverse_step
+        self.tables, self.K = tables, tables.K
+        dev = torch.device(device)
+        self.x = torch.zeros((batch_size, seq_len), dtype=torch.long, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        steps = list(range(timesteps - 1, 0, -1))
+        # inputs of the captured launches: they must stay allocated as long as the graph is replayed
+        self.tts = tts = [torch.full((batch_size,), t, dtype=torch.long, device=dev) for t in steps]
+        self.model_fn = model_fn
+        self.stride = 4 * len(steps)
+
+        def body():
+            s = self.x
+            for i, tt in enumerate(tts):
+                s = reverse_step(tables, model_fn(s, tt), s, tt, rng=(seed, 4 * i, self.counter))
+            return s
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                reverse_step(tables, model_fn(self.x, tts[0]), self.x, tts[0], rng=(seed, 0, self.counter))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = body()
+
+    def sample(self, x_init=None):
+        if x_init is None:
+            self.x.random_(0, self.K)
+        else:
+            self.x.copy_(x_init)
+        self.counter.add_(self.stride)
+        self.graph.replay()
+        return self.out

@@ -12,13 +12,15 @@ from .._lib import lib, check, ptr, stream_ptr
 from ..tables import protein_tables
 
 
-def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, exclude_last_prefix=0):
+def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, exclude_last_prefix=0, rng=None):
     """x_{t-1} for a batch (generate.py:28-41): predictions [B,L,n_tokens]
     float32 logits, x_t [B,L] int64, t [B] int64; ``noise`` optionally the
     Exp(1) draws [B,L,K] float64 of the reference's multinomial.  The last two
     arguments are the MSA sampler's gap handling (generate.py:84-88): the last
     class is divided by ``last_class_div`` and cannot be drawn in the first
-    ``exclude_last_prefix`` positions of each batch element."""
+    ``exclude_last_prefix`` positions of each batch element.  ``rng=(seed, offset,
+    counter)`` names the Philox stream explicitly, ``counter`` a one-element int64
+    device tensor added to ``offset`` on the device (HIP-graph capture)."""
     from ..d3pm.diffusion_discrete import _philox_ticket
     _lib.require_device(predictions, x_t)
     pr = predictions.contiguous()
@@ -29,16 +31,19 @@ def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, ex
     B = x_t.shape[0]
     npos = x_t.numel() // max(B, 1)
     seed = off = 0
-    if noise is None:
-        seed, off = _philox_ticket(x_t.device)
-    else:
+    counter = None
+    if noise is not None:
         noise = noise.to(device=x_t.device, dtype=torch.float64).contiguous()
         assert noise.shape == x_t.shape + (tables.K,), noise.shape
+    elif rng is not None:
+        seed, off, counter = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]), rng[2]
+    else:
+        seed, off = _philox_ticket(x_t.device)
     out = torch.empty_like(x_t)
     with torch.cuda.device(x_t.device):
         check(lib.d3pm_lvb_reverse_step(tables.desc(), ptr(pr), pr.shape[-1], ptr(x_t), ptr(t), B, npos, ptr(noise),
-                                        seed, off, float(last_class_div), int(exclude_last_prefix), ptr(out),
-                                        stream_ptr()))
+                                        seed, off, ptr(counter), float(last_class_div), int(exclude_last_prefix),
+                                        ptr(out), stream_ptr()))
     return out
 
 

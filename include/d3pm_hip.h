@@ -226,15 +226,17 @@ int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const i
 /* Reverse step of generate_d3pm (generate.py:28-40) and of generate_msa_d3pm
  * (generate.py:70-93): x_{t-1} = argmax_j(P_j / E_j), P the normalised p-squared
  * marginal; expo float64 [B,npos,K] holds the Exp(1) draws E, or is NULL for
- * on-device noise (seed, offset).  t int64 [B].
+ * on-device noise: Philox stream (seed, offset + *offset_dev), offset_dev a
+ * device counter or NULL (as in d3pm_q_sample; lets a captured HIP graph draw
+ * fresh noise on every replay).  t int64 [B].
  *   last_class_div: P[K-1] is divided by this (1 + penalty_value of the MSA
  *     sampler, generate.py:84-86; 1.0 otherwise)
  *   exclude_last_prefix: class K-1 cannot be drawn at positions < this (the
  *     query row of an MSA, generate.py:88; 0 otherwise) */
 int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,
                           const int64_t* t, int B, long npos, const double* expo, uint64_t seed,
-                          uint64_t offset, double last_class_div, long exclude_last_prefix,
-                          int64_t* out, void* stream);
+                          uint64_t offset, const uint64_t* offset_dev, double last_class_div,
+                          long exclude_last_prefix, int64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -296,3 +296,29 @@ def test_custom_mutant_matrix_golden(pkg, tmp_path):
                          filename_prefix=str(tmp_path / "out"))
     lines = (tmp_path / "out_samples-1_elbo_predictions.csv").read_text().splitlines()
     assert [l.split(";")[0] for l in lines] == desc
+
+
+def test_graphed_reverse_sampler(pkg):
+    from d3pm_amd.graphs import GraphedReverseSampler
+    from d3pm_amd.protein_generation.generate import reverse_step
+    from d3pm_amd.tables import protein_tables
+    tok = pkg.Tokenizer()
+    T, B, L = 20, 6, 48
+    Qb, Qt = tok.q_uniform_schedule(num_steps=T, device=DEV)
+    tb = protein_tables(Qt, Qb)
+    g = golden("protein_generate")
+    emb, tvec = T_(g["emb"]), T_(g["tvec"])
+    model = lambda x, tt: emb[x] + tvec[tt][:, None, :]
+    smp = GraphedReverseSampler(tb, model, B, L, T, DEV, seed=9)
+    x_init = torch.randint(0, 22, (B, L), device=DEV)
+    a = smp.sample(x_init).clone()
+    counter_a = int(smp.counter.item())
+    b = smp.sample(x_init).clone()
+    assert a.shape == (B, L) and int(a.min()) >= 0 and int(a.max()) < 22 and not torch.equal(a, b)
+    # the replay equals the same loop launched step by step on the same Philox stream
+    c = torch.full((1,), counter_a, dtype=torch.int64, device=DEV)
+    s = x_init.clone()
+    for i, t in enumerate(range(T - 1, 0, -1)):
+        tt = torch.full((B,), t, dtype=torch.long, device=DEV)
+        s = reverse_step(tb, model(s, tt), s, tt, rng=(9, 4 * i, c))
+    assert torch.equal(s, a)
