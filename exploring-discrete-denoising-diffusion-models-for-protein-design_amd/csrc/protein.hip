@@ -299,11 +299,28 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   if (offset_dev) offset += *offset_dev;
   constexpr int WAVES = PBLOCK / 64, TPW = 64 / L::G;      // tokens per wave and pass
   constexpr int REFILL = 256 / TPW;                         // passes served by one pool
+  constexpr int PF = 3;                                     // passes whose rows are in flight
   __shared__ uint32_t pool[WAVES][256];
+  __shared__ float s_ad[256], s_ao[256];                    // column x_t of Q_t: diagonal / off-diagonal entry by x_t
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tok_in_wave = lane / L::G;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  const long pbeg = chunk * a.chunk_pos + slot;
+  constexpr long STEP = PBLOCK / L::G;
+  // rows and tokens of the first passes are requested before the timestep -> digest chain
+  float zq[PF][L::V];
+  int xq[PF];
+  auto fetch = [&](int u, long pos) {
+    const long n = (long)b * a.npos + (pos < p1 ? pos : pbeg < p1 ? pbeg : 0);
+    load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, zq[u]);
+    xq[u] = (int)a.xt[n];
+  };
+  if (pbeg < p1 || chunk * a.chunk_pos < p1) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(u, pbeg + u * STEP);
+  }
   const int t = (int)a.t[b];
   float md[L::V], mo[L::V];
 #pragma unroll
@@ -312,46 +329,54 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
     md[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
     mo[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
   }
+  for (int c = threadIdx.x; c < K; c += PBLOCK) {
+    s_ad[c] = (float)dgd(a.tb.qone_digest, t, 0, K)[c];
+    s_ao[c] = (float)dgd(a.tb.qone_digest, t, 1, K)[c];
+  }
+  __syncthreads();
   const float inv_last = 1.0f / last_class_div;
-  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   int it = 0;
-  for (long pos0 = chunk * a.chunk_pos; pos0 < p1; pos0 += PBLOCK / L::G, ++it) {
-    if (it % REFILL == 0) {          // wave-private pool: no workgroup barrier needed, LDS ops of a wave are in order
-      const U4 r = philox4x32_10(((uint64_t)blockIdx.x << 32) + (uint64_t)(it / REFILL) * PBLOCK + threadIdx.x, offset,
-                                 seed);
-      pool[wave][lane] = r.x; pool[wave][64 + lane] = r.y; pool[wave][128 + lane] = r.z; pool[wave][192 + lane] = r.w;
-    }
-    const long pos = pos0 + slot;
-    if (pos >= p1) continue;         // whole lane groups leave together
-    const long n = (long)b * a.npos + pos;
-    const int xt = (int)a.xt[n];
-    float z[L::V];
-    load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
-    const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
-    float m = -INFINITY;
+  for (long pos0 = chunk * a.chunk_pos; pos0 < p1; pos0 += PF * STEP) {
 #pragma unroll
-    for (int v = 0; v < L::V; ++v) m = fmaxf(m, (L::cls(g, v) < K) ? z[v] : -INFINITY);
-    m = group_max<L::G>(m);
-    float p[L::V], s2 = 0;
+    for (int u = 0; u < PF; ++u, ++it) {
+      if (pos0 + u * STEP >= p1) break;                      // uniform over the workgroup
+      if (it % REFILL == 0) {        // wave-private pool: LDS operations of a wave are in order
+        const U4 r = philox4x32_10(((uint64_t)blockIdx.x << 32) + (uint64_t)(it / REFILL) * PBLOCK + threadIdx.x, offset,
+                                   seed);
+        pool[wave][lane] = r.x; pool[wave][64 + lane] = r.y; pool[wave][128 + lane] = r.z; pool[wave][192 + lane] = r.w;
+      }
+      const long pos = pos0 + u * STEP + slot;
+      float z[L::V];
 #pragma unroll
-    for (int v = 0; v < L::V; ++v) {
-      p[v] = (L::cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
-      s2 = fmaf(p[v], p[v], s2);
-    }
-    s2 = group_sum<L::G>(s2);       // the softmax normaliser cancels in the draw: p stays unnormalised
-    const float a_diag = (float)dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = (float)dgd(a.tb.qone_digest, t, 1, K)[xt];
-    const bool no_last = pos < exclude_last_prefix;
-    float r[L::V];
+      for (int v = 0; v < L::V; ++v) z[v] = zq[u][v];
+      const int xt = xq[u];
+      if (pos + PF * STEP - slot < p1) fetch(u, pos + PF * STEP);   // refill this stage (uniform condition)
+      const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
+      float m = -INFINITY;
 #pragma unroll
-    for (int v = 0; v < L::V; ++v) {
-      const int c = L::cls(g, v);
-      const float pp = p[v] * p[v];
-      r[v] = (c < K) ? ((c == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp) : 0.0f;
-      if (c == K - 1) r[v] = no_last ? 0.0f : r[v] * inv_last;
+      for (int v = 0; v < L::V; ++v) m = fmaxf(m, (L::cls(g, v) < K) ? z[v] : -INFINITY);
+      m = group_max<L::G>(m);
+      float p[L::V], s2 = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        p[v] = (L::cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
+        s2 = fmaf(p[v], p[v], s2);
+      }
+      s2 = group_sum<L::G>(s2);       // the softmax normaliser cancels in the draw: p stays unnormalised
+      const float a_diag = s_ad[xt], a_off = s_ao[xt];
+      const bool no_last = pos < exclude_last_prefix;
+      float r[L::V];
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const int c = L::cls(g, v);
+        const float pp = p[v] * p[v];
+        r[v] = (c < K) ? ((c == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp) : 0.0f;
+        if (c == K - 1) r[v] = no_last ? 0.0f : r[v] * inv_last;
+      }
+      const float u01v = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+      const int pick = group_pick<L::G, L::V>(r, g, u01v, xt, [](int gg, int vv) { return L::cls(gg, vv); });
+      if (g == 0 && pos < p1) out[(long)b * a.npos + pos] = pick;
     }
-    const float u = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
-    const int pick = group_pick<L::G, L::V>(r, g, u, xt, [](int gg, int vv) { return L::cls(gg, vv); });
-    if (g == 0) out[n] = pick;
   }
 }
 
@@ -439,10 +464,30 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   D3PM_CHECK_ARG(last_class_div > 0.0 && exclude_last_prefix >= 0, "last-class divisor must be positive, prefix >= 0");
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
+  if (!expo && ld <= 32) {
+    // few lanes per token: the draw is cheap per class, the cross-lane steps are what costs
+    static const int rev_blocks = getenv("D3PM_REV_BLOCKS") ? atoi(getenv("D3PM_REV_BLOCKS")) : 1024;
+    static const int rev_lanes = getenv("D3PM_REV_LANES") ? atoi(getenv("D3PM_REV_LANES")) : 4;
+    auto launch = [&](auto lay) {
+      using L = decltype(lay);
+      ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
+      const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, rev_blocks);   // long trips: rows are prefetched 3 passes ahead
+      a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
+      hipLaunchKernelGGL(k_lvb_reverse_device_noise<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred,
+                         ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
+      return D3PM_OK;
+    };
+    if (rev_lanes == 2) return ld <= 24 ? launch(Layout<2, 12, false>{}) : launch(Layout<2, 16, false>{});
+    if (rev_lanes == 4) return ld <= 24 ? launch(Layout<4, 6, false>{}) : launch(Layout<4, 8, false>{});
+    return ld <= 24 ? launch(Layout<8, 3, false>{}) : launch(Layout<8, 4, false>{});
+  }
   return dispatch_layout(tb->K, false, [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
     if (!expo) {
+      const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, 1024);
+      a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
       hipLaunchKernelGGL(k_lvb_reverse_device_noise<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred,
                          ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
       D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
