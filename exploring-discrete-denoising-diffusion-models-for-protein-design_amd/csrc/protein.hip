@@ -21,7 +21,7 @@ struct ProtArgs {
 };
 
 __device__ __forceinline__ const double* dgd(const double* digest, int t, int c, int K) {
-  return digest + ((size_t)t * 2 + c) * K;
+  return digest + ((size_t)t * 4 + c) * K;        // c: 0 diag, 1 off, 2 log(diag), 3 log(off)
 }
 
 template <class L>
@@ -76,6 +76,34 @@ __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __
 }
 
 // ------------------------------------------------------------------ shared maths
+// 1/x in float64 from the hardware estimate and two Newton steps (error of the
+// order of 1e-16 relative, not correctly rounded; a third of the cost of a division).
+__device__ __forceinline__ double rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// Natural logarithm of a positive normal float64 (the argument-reduction and
+// polynomial of the classic fdlibm e_log.c algorithm, error below 1 ulp with an
+// exact division; here the division is rcp64, which adds about 1e-16 relative).
+// A third of the instructions of the library routine, which also handles zero,
+// negative, infinite and subnormal arguments -- those are sent to it.
+__device__ __forceinline__ double log64(double x) {
+  if (!(x >= 2.2250738585072014e-308 && x < 1.7976931348623157e308)) return log(x);
+  int e;
+  double m = frexp(x, &e);                       // [0.5, 1)
+  if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+  const double f = m - 1.0, dk = (double)e;
+  const double sq = f * rcp64(2.0 + f), z = sq * sq, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 // float32 softmax over the first K logits, promoted to float64.
 template <class L>
 __device__ __forceinline__ void softmax_f32_to_f64(const float (&z)[L::V], int g, int K, double (&p)[L::V]) {
@@ -127,10 +155,12 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
   const int t = (int)a.t[b];
   const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
-  double md[L::V], mo[L::V];
+  double md[L::V], mo[L::V], lmd[L::V], lmo[L::V];
   if (branch == 2) {
     load_digest_d<L>(a.tb.qbar_digest, t - 1, 0, K, g, md);
     load_digest_d<L>(a.tb.qbar_digest, t - 1, 1, K, g, mo);
+    load_digest_d<L>(a.tb.qbar_digest, t - 1, 2, K, g, lmd);
+    load_digest_d<L>(a.tb.qbar_digest, t - 1, 3, K, g, lmo);
   }
   const double cscale = grad_scale / (double)a.npos;
   double acc = 0;
@@ -175,32 +205,57 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
       // finalize step does), but only the depth D for an MSA laid out [D,L,K]
       tok_loss = group_sum<L::G>(s) * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
     } else {
+      // KL(q(x_{t-1} | x_t, x_0) || p_theta(x_{t-1} | x_t)) (losses.py:62-86), with
+      //   post_j = A_j B_j / den,  P_j = A_j s_j / rsum,  s_j = off_j (S2 - p_j^2) + diag_j p_j^2
+      // (A: column x_t of Q_t, B: row x0 of Qbar_{t-1}; both take their diagonal or off-diagonal value).  A_j
+      // cancels inside the logarithm and log B_j, log den come from the digests, so a class costs one float64
+      // log (of s_j) and, for the gradient, one reciprocal:
+      //   term_j = post_j (log B_j - log den + log rsum - log s_j)
       const int xt = (int)a.xt[n];
       load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
-      double p[L::V], A[L::V], r[L::V], rsum;
+      double p[L::V];
       softmax_f32_to_f64<L>(z, g, K, p);
       const double a_diag = dgd(a.tb.qone_digest, t, 0, K)[xt], a_off = dgd(a.tb.qone_digest, t, 1, K)[xt];
-      marginal<L>(p, md, mo, a_diag, a_off, xt, g, K, A, r, rsum);
       // denominator Qbar_t[x0, x_t] (MSA variant: Qbar_{t-1}[x0, x_t], losses.py:148)
       const int td = msa ? t - 1 : t;
-      const double den = dgd(a.tb.qbar_digest, td, (x0 == xt) ? 0 : 1, K)[xt];
-      double post[L::V], s = 0, psum = 0;
+      const int dsel = (x0 == xt) ? 0 : 1;
+      const double den = dgd(a.tb.qbar_digest, td, dsel, K)[xt], lden = dgd(a.tb.qbar_digest, td, 2 + dsel, K)[xt];
+      const double iden = rcp64(den);
+      double s2 = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) s2 += p[v] * p[v];
+      s2 = group_sum<L::G>(s2);
+      double A[L::V], sj[L::V], post[L::V], rs = 0, psum = 0;
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
         const int c = L::cls(g, v);
-        post[v] = (c < K) ? A[v] * ((c == x0) ? md[v] : mo[v]) / den : 0.0;
+        const bool ok = c < K;
+        const double pp = p[v] * p[v];
+        A[v] = (c == xt) ? a_diag : a_off;
+        sj[v] = ok ? mo[v] * (s2 - pp) + md[v] * pp : 1.0;
+        post[v] = ok ? A[v] * ((c == x0) ? md[v] : mo[v]) * iden : 0.0;
+        rs += ok ? A[v] * sj[v] : 0.0;
         psum += post[v];
-        if (c < K) s += (post[v] > 0.0 ? post[v] * log(post[v]) : 0.0) - post[v] * log(r[v] / rsum);
+      }
+      const double rsum = group_sum<L::G>(rs);
+      const double lshift = log64(rsum) - lden;
+      double s = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const double lB = (L::cls(g, v) == x0) ? lmd[v] : lmo[v];
+        s += (post[v] > 0.0) ? post[v] * ((lB + lshift) - log64(sj[v])) : 0.0;
       }
       tok_loss = group_sum<L::G>(s);
       if constexpr (GRAD) {
         psum = group_sum<L::G>(psum);
+        const double base = psum * rcp64(rsum);
         double gs[L::V], W = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
-          const bool ok = L::cls(g, v) < K;
-          const double gr = ok ? (-post[v] / r[v] + psum / rsum) * cscale : 0.0;
-          gs[v] = gr * A[v];
+          const int c = L::cls(g, v);
+          // d term / d r_j times A_j:  (-post_j / r_j + psum / rsum) A_j, post_j / r_j = B_j / (den s_j)
+          const double Bc = (c == x0) ? md[v] : mo[v];
+          gs[v] = (c < K) ? (base - Bc * iden * rcp64(sj[v])) * cscale * A[v] : 0.0;
           W += gs[v] * mo[v];
         }
         W = group_sum<L::G>(W);
@@ -435,7 +490,7 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
   hipStream_t s = (hipStream_t)stream;
   // sample_prior builds a float32 1/K and takes its float32 log (losses.py:11-12,60)
   const double log_prior = (double)logf(1.0f / (float)tb->K);
-  return dispatch_layout((int)ld, false, [&](auto lay) {
+  auto run = [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, L::G);
     const size_t need = (size_t)B * a.chunks * sizeof(double);
@@ -452,7 +507,8 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
     hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);
     D3PM_LAUNCH_CHECK("k_lvb_finalize");
     return D3PM_OK;
-  });
+  };
+  return dispatch_layout((int)ld, false, run);       // (four lanes per token measured no faster than eight)
 }
 
 extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,

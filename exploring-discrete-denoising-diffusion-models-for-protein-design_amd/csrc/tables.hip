@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
   const int t = blockIdx.x;
   const double* m = table + (long)t * st;
   constexpr bool F32 = sizeof(OutT) == 4;
-  constexpr int NV = F32 ? 4 : 2;
+  constexpr int NV = 4;                 // diag, off, log(diag [+eps]), log(off [+eps])
   OutT* dg = digest + (size_t)t * NV * K;
   int bad = 0;
   for (int e = threadIdx.x; e < K * K; e += blockDim.x) {
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
         dg[2 * K + j] = (float)log((double)(d + (float)tol_or_eps));
       } else {
         dg[0 * K + j] = x;
+        dg[2 * K + j] = log(x);          // -inf for a zero entry: readers mask on the probability
       }
     } else {
       if constexpr (F32) {
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
           dg[3 * K + j] = (float)log((double)(o + (float)tol_or_eps));
         } else {
           dg[1 * K + j] = x;
+          dg[3 * K + j] = log(x);
         }
       }
     }

@@ -89,8 +89,8 @@ class ProteinTables:
         T, K = self.T, self.K
         with torch.cuda.device(self.device):
             s = stream_ptr()
-            self.qbar_digest = torch.empty((T, 2, K), dtype=torch.float64, device=self.device)
-            self.qone_digest = torch.empty((T, 2, K), dtype=torch.float64, device=self.device)
+            self.qbar_digest = torch.empty((T, 4, K), dtype=torch.float64, device=self.device)
+            self.qone_digest = torch.empty((T, 4, K), dtype=torch.float64, device=self.device)
             viol = torch.zeros(2, dtype=torch.int32, device=self.device)
             check(lib.d3pm_digest_f64(ptr(Q_bar), *_strides3(Q_bar), T, K, self.RTOL, ptr(self.qbar_digest),
                                       viol.data_ptr(), s))

@@ -86,8 +86,8 @@ int d3pm_cumprod_f64(int K, int T, const double* mats, long st, long sr, long sc
 int d3pm_digest_f32(const double* table, long st, long sr, long sc, int T, int K, float eps,
                     float* digest, int* violations, void* stream);
 
-/* Same test in float64 with a relative tolerance; digest float64 [T][2][K]:
- * diag, off.  For the protein-style kernels, which compute in float64
+/* Same test in float64 with a relative tolerance; digest float64 [T][4][K]:
+ * diag, off, log(diag), log(off) (no eps).  For the protein-style kernels, which compute in float64
  * (protein_generation/losses.py:65). */
 int d3pm_digest_f64(const double* table, long st, long sr, long sc, int T, int K, double rtol,
                     double* digest, int* violations, void* stream);
@@ -113,8 +113,8 @@ typedef struct d3pm_tables_f32 {
 /* Float64 view for the protein-style kernels (structured only). */
 typedef struct d3pm_tables_f64 {
   int K, T;
-  const double* qbar_digest; /* [T][2][K] of Q_bar */
-  const double* qone_digest; /* [T][2][K] of Q_t   */
+  const double* qbar_digest; /* [T][4][K] of Q_bar: diag, off, log(diag), log(off) */
+  const double* qone_digest; /* [T][4][K] of Q_t   */
 } d3pm_tables_f64;
 
 /* ------------------------------------------------------------------------
