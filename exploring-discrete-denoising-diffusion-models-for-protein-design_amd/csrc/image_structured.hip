@@ -126,6 +126,12 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
   const float eps = a.tb.eps;
   if (offset_dev) offset += *offset_dev;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  const long pfirst = chunk * a.chunk_pos + threadIdx.x;
+  // the first token's load is in flight, and its random words are computed, while the
+  // timestep -> digest -> prefix-sum chain runs
+  int x0_next = 0;
+  if (pfirst < p1) x0_next = load_tok(a.x0, (long)b * a.npos + pfirst, a.x0_bytes);
   int t;
   if (t_draw) {
     t = draw_timestep(b, a.tb.T, offset, seed);
@@ -154,14 +160,26 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
       if (j < K) cdf[j + 1] = run;
     }
   }
-  for (int j = threadIdx.x; j < K; j += blockDim.x) dmo[j] = dgd_[j] - dgo_[j];
+  float dmo_mine[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = threadIdx.x + i * BLOCK;
+    dmo_mine[i] = j < K ? dgd_[j] - dgo_[j] : 0.0f;
+  }
+  U4 r_next = philox4x32_10((uint64_t)((long)b * a.npos + pfirst), offset, seed);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (threadIdx.x + i * BLOCK < K) dmo[threadIdx.x + i * BLOCK] = dmo_mine[i];
   __syncthreads();
   const float total = cdf[K];
-  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
-  for (long pos = chunk * a.chunk_pos + threadIdx.x; pos < p1; pos += blockDim.x) {
+  for (long pos = pfirst; pos < p1; pos += blockDim.x) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
-    const U4 r4 = philox4x32_10((uint64_t)n, offset, seed);
+    const int x0 = x0_next;
+    const U4 r4 = r_next;
+    if (pos + blockDim.x < p1) {
+      x0_next = load_tok(a.x0, n + blockDim.x, a.x0_bytes);
+      r_next = philox4x32_10((uint64_t)(n + blockDim.x), offset, seed);
+    }
     const float extra = dmo[x0];
     const double r = u01d_open(r4.x, r4.y) * ((double)total + (double)extra);
     const double lo = cdf[x0], hi = (double)cdf[x0 + 1] + (double)extra;
