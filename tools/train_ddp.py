@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Data-parallel training harness around the D3PM core: a ByteNet-like denoiser in
+stock PyTorch, the two-launch training step of this package for everything
+between data and logits gradient, DistributedDataParallel for the denoiser's
+gradients (the core itself has no parameters and no collective).
+
+    python tools/train_ddp.py --steps 30                              # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port 29511 tools/train_ddp.py --steps 30               # N GPUs, RCCL
+
+Prints one JSON line (rank 0): step time, the share of the step spent in the path
+(corruption + fused loss, measured with HIP events on the launch stream), and the
+share added by the gradient all-reduce (step time with and without `no_sync`).
+Per-rank normalisation is the reference's: every rank averages over its local batch
+and DDP averages the gradients, which reproduces the global-batch mean.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+class Block(nn.Module):
+    def __init__(self, d, dilation):
+        super().__init__()
+        self.n1, self.n2 = nn.LayerNorm(d), nn.LayerNorm(d // 2)
+        self.down, self.up = nn.Linear(d, d // 2), nn.Linear(d // 2, d)
+        self.conv = nn.Conv1d(d // 2, d // 2, 5, padding=2 * dilation, dilation=dilation)
+
+    def forward(self, x):                               # [B, L, d]
+        h = self.down(torch.nn.functional.gelu(self.n1(x)))
+        h = self.conv(torch.nn.functional.gelu(self.n2(h)).transpose(1, 2)).transpose(1, 2)
+        return x + self.up(torch.nn.functional.gelu(h))
+
+
+class ByteNetLike(nn.Module):
+    """Token + timestep embedding, dilated residual conv blocks, linear head."""
+
+    def __init__(self, K, T, d=256, layers=8):
+        super().__init__()
+        self.tok, self.time = nn.Embedding(K, d), nn.Embedding(T + 1, d)
+        self.blocks = nn.ModuleList(Block(d, 2 ** (i % 5)) for i in range(layers))
+        self.norm, self.head = nn.LayerNorm(d), nn.Linear(d, K)
+
+    def forward(self, x, t):                            # x [B, L, 1, 1] int64, t [B]
+        shape = x.shape
+        h = self.tok(x.reshape(shape[0], -1)) + self.time(t.long())[:, None, :]
+        for b in self.blocks:
+            h = b(h)
+        return self.head(self.norm(h)).reshape(*shape, -1).float()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=263)
+    ap.add_argument("--bits", type=int, default=5, help="K = 2**bits classes")
+    ap.add_argument("--d-model", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, one rank per GPU)")
+    ap.add_argument("--bf16", action="store_true", help="autocast the denoiser to bfloat16 (the path stays float32)")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = torch.cuda.device_count()
+    dev = torch.device("cuda", local % max(ngpu, 1))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+
+    import d3pm_amd
+    K, T, B, L = 2 ** args.bits, 500, args.batch_per_gpu, args.seq_len
+    torch.manual_seed(1234)                                   # same initial weights on every rank
+    model = ByteNetLike(K, T, args.d_model, args.layers).to(dev)
+    net = nn.parallel.DistributedDataParallel(model, device_ids=None if args.backend == "gloo" else [dev.index]) \
+        if world > 1 else model
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform",
+                                   num_bits=args.bits, transition_bands=None, model_prediction="x_start",
+                                   model_output="logits", loss_type="hybrid", hybrid_coeff=0.001, device=dev)
+    torch.manual_seed(99 + rank)                              # different data and noise per rank
+    data = torch.randint(0, K, (B, L, 1, 1), device=dev)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    path_ms = []
+
+    def model_fn(x, t):
+        ev[1].record()                                        # corruption done
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
+            out = net(x, t)
+        ev[2].record()                                        # logits ready: the loss follows
+        return out
+
+    def step(sync=True):
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        ctx = net.no_sync() if (world > 1 and not sync) else contextlib.nullcontext()
+        with ctx:
+            out = d.training_step(model_fn, x_start=data)     # backward through the denoiser included
+        opt.step()
+        return out
+
+    def timed(n, sync=True):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step(sync)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / n * 1e3, out
+
+    for _ in range(args.warmup):
+        step()
+    ms, out = timed(args.steps)
+    # share of the path: corruption (ev0 -> ev1) measured inside a step; the fused loss + mean by direct timing
+    torch.cuda.synchronize()
+    corrupt_ms = ev[0].elapsed_time(ev[1])
+    with torch.no_grad():
+        logits = net(out["x_t"], out["t"]).detach()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    frozen = lambda x, t: logits
+    d.training_step(frozen, x_start=data, backward=False)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(20):
+        d._fused(logits.requires_grad_(True), data, out["x_t"], out["t"], "hybrid")
+    e1.record(); torch.cuda.synchronize()
+    loss_ms = e0.elapsed_time(e1) / 20
+    nosync_ms = timed(args.steps, sync=False)[0] if world > 1 else ms
+    losses = out["losses"].double().mean()
+    if world > 1:
+        dist.all_reduce(losses)
+        losses /= world
+    if rank == 0:
+        print(json.dumps({
+            "what": "DDP training step: ByteNet-like denoiser (stock PyTorch) + D3PM training_step (this package)",
+            "n_gpus": world, "backend": args.backend if world > 1 else None, "global_batch": B * world, "seq_len": L,
+            "K": K, "denoiser": {"d_model": args.d_model, "layers": args.layers, "bf16": args.bf16,
+                                 "params": sum(p.numel() for p in model.parameters())},
+            "ms_per_step": ms, "tokens_per_s": B * L * world / (ms * 1e-3),
+            "path_ms": {"corrupt_and_timestep_draw": corrupt_ms, "fused_loss_fwd_bwd": loss_ms},
+            "path_share": (corrupt_ms + loss_ms) / ms,
+            "allreduce_share": max(0.0, (ms - nosync_ms) / ms) if world > 1 else 0.0,
+            "mean_loss_bits_per_dim": float(losses.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
