@@ -13,12 +13,15 @@ namespace d3pm {
 constexpr int next_pow2_c(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 // MFMA = true: K = 256 only; the contraction runs on v_mfma_f32_32x32x2_f32 over
-// tiles of 32 tokens whose LDS rows are padded by 16 bytes (conflict-free
-// ds_read_b128 of the A fragments).
+// tiles of 64 tokens (every table element fetched from L2 feeds two matrix
+// instructions) whose LDS rows are padded by 16 bytes (conflict-free
+// ds_read_b128 of the A fragments).  One 65 KB LDS buffer per workgroup and at
+// most 256 registers per lane, so two workgroups share a CU and one's per-token
+// phases run under the other's contraction.
 template <class L, bool MFMA = false>
 struct DenseCfg {
   static constexpr int TPP = BLOCK / L::G;              // tokens per epilogue pass
-  static constexpr int TM = MFMA ? 32 : (TPP > 16 ? TPP : 16);   // tokens per tile
+  static constexpr int TM = MFMA ? 64 : (TPP > 16 ? TPP : 16);   // tokens per tile
   static constexpr int PAD = MFMA ? 4 : 0;              // floats of padding per LDS row
   static constexpr int KC = next_pow2_c(L::G * L::V);   // threads per token group in the contraction
   static constexpr int CG = BLOCK / KC;                 // token groups
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(BLOCK) void k_dense_q_sample(ImgArgs a, const float
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
       const int c = L::cls(g, v);
-      const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]);
+      const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v]
+                        : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v]));
       const float val = logf(p[v] + eps) + gum;
       if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
     }
@@ -191,9 +195,10 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-  // M[128h + s][64w + r (+32)] through the wave-uniform base and a 32-bit byte offset
-  const char* Mb = reinterpret_cast<const char*>(M);
-  const unsigned boff = (unsigned)(((128 * h) * K + 64 * wave + r) * 4);
+  // M[128h + s][64w + r (+32)] through a buffer descriptor: per-lane 32-bit byte offset, the group's row offset in
+  // a scalar register and the rest in the instruction's immediate field, so the loop carries no address registers
+  const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, K * K * 4, 0x00020000);
+  const int boff = ((128 * h) * K + 64 * wave + r) * 4;
   const float* arow = in + (size_t)r * LDK + 128 * h;                 // in[r (+32 rt)][128h + s]
   // groups of GS reduction steps; the B operands of the next group are requested
   // before the current group's MFMAs (GS * RT * 2 * 64 cycles of cover)
@@ -201,9 +206,10 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
   auto load_b = [&](float (&b)[GS][2], int grp) {
 #pragma unroll
     for (int q = 0; q < GS; ++q) {
-      const unsigned o = boff + (unsigned)((grp * GS + q) * K * 4);
-      b[q][0] = *reinterpret_cast<const float*>(Mb + o);
-      b[q][1] = *reinterpret_cast<const float*>(Mb + (o + 128u));
+      const int so = (grp * GS + (q / 4) * 4) * K * 4;      // immediates reach 4095 bytes: four rows
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        b[q][ct] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Mrs, boff + ((q % 4) * K + 32 * ct) * 4, so, 0));
     }
   };
   auto load_a = [&](float4 (&av)[RT][GS / 4], int grp) {
@@ -285,14 +291,19 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   using C = DenseCfg<L, MFMA>;
   extern __shared__ float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
+  // matrix-core path: per-token scalars (x0, x_t | CE term, softmax max, 1 / sum) live here between phases
+  // instead of in registers, which are what limits two workgroups per CU
+  __shared__ int s_toki[MFMA ? 2 * C::TM : 1];
+  __shared__ float s_tokf[MFMA ? 3 * C::TM : 1];
   const int K = a.tb.K;
   const int LDK = K + C::PAD;              // LDS row stride
   const float eps = a.tb.eps;
-  float* s_pi = lds;                         // [TM][LDK] softmax(z)
-  float* s_f2 = lds + (size_t)C::TM * LDK;   // [TM][LDK] pi @ Qm, later d loss / d f2
-  // d loss / d pi (GRAD only): its own buffer, or on the matrix-core path the
-  // buffer of d loss / d f2, which the contraction has consumed by then
-  float* s_gp = MFMA ? s_f2 : s_f2 + (size_t)C::TM * LDK;
+  // VALU path: softmax(z), pi @ Qm (later d loss / d f2) and d loss / d pi in buffers of their own.  Matrix-core
+  // path: ONE [TM][LDK] buffer that every phase transforms in place (the contraction reads all its operands before
+  // it writes); the softmax needed again by the backward phase is recomputed from the logits.
+  float* s_pi = lds;
+  float* s_f2 = MFMA ? lds : lds + (size_t)C::TM * LDK;
+  float* s_gp = MFMA ? lds : s_f2 + (size_t)C::TM * LDK;
   // Workgroups are dealt to the 8 XCDs round-robin by index; all chunks of a batch
   // element go to the same XCD so that its two 256 KB matrices (one timestep) are
   // fetched into one L2 only.  The grid is B rounded up to a multiple of 8.
@@ -333,43 +344,58 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   // their indices stay in registers.  Global reads run ahead of their use by a whole phase: a tile's logits rows
   // and tokens are requested during the previous tile's second contraction (or before its first, without a
   // backward pass), the table rows of the epilogue before the first contraction.
+  // On the matrix-core path nothing is carried across a contraction: rows, tokens and table rows are requested one
+  // pass ahead inside each phase through two rolling buffers (the next tile's first pass during this tile's last),
+  // and the backward phase re-reads the tile's logits rows.
   constexpr int NP = C::TM / C::TPP;       // passes per phase
-  float zn[NP][L::V];
-  int x0n[NP], xtn[NP];
+  constexpr int NZ = MFMA ? 2 : NP;        // buffers for rows, tokens, table rows
+  float zn[NZ][L::V];
+  int x0n[NZ], xtn[NZ];
+  auto row_index = [&](long tile, int ps) {
+    const long pos = tile + ps * C::TPP + slot;
+    return (long)b * a.npos + (pos < p1 ? pos : tile);
+  };
+  auto fetch_row = [&](long tile, int ps) { load_slots<L>(e.logits + row_index(tile, ps) * e.ld, g, K, -INFINITY, zn[ps % NZ]); };
+  auto fetch_pass = [&](long tile, int ps) {
+    const long n = row_index(tile, ps);
+    fetch_row(tile, ps);
+    xtn[ps % NZ] = load_tok(a.xt, n, a.xt_bytes);
+    x0n[ps % NZ] = (MODE == DENSE_LOSS) ? load_tok(a.x0, n, a.x0_bytes) : 0;
+  };
   auto fetch_tile = [&](long tile) {
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const long pos = tile + ps * C::TPP + slot;
-      const long n = (long)b * a.npos + (pos < p1 ? pos : tile);
-      load_slots<L>(e.logits + n * e.ld, g, K, -INFINITY, zn[ps]);
-      xtn[ps] = load_tok(a.xt, n, a.xt_bytes);
-      x0n[ps] = (MODE == DENSE_LOSS) ? load_tok(a.x0, n, a.x0_bytes) : 0;
-    }
+    for (int ps = 0; ps < (MFMA ? 1 : NP); ++ps) fetch_pass(tile, ps);
   };
   fetch_tile(chunk * a.chunk_pos);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += C::TM) {
     // ---- phase 1: softmax of the tile's logits into LDS, CE term
-    float zkeep[NP][L::V];   // logits of this lane's tokens (only used at t == 0 / POST)
+    constexpr int NKEEP = MFMA ? 1 : NP;
+    float zkeep[NKEEP][L::V];   // VALU path: logits of this lane's tokens (used at t == 0); matrix-core path: re-read
     float cekeep[NP];
     int x0c[NP], xtc[NP];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int tok = ps * C::TPP + slot;
       const bool live = tile0 + tok < p1;
-      x0c[ps] = x0n[ps]; xtc[ps] = xtn[ps];
-      float pi[L::V];
-      float m = zn[ps][0];
+      x0c[ps] = x0n[ps % NZ]; xtc[ps] = xtn[ps % NZ];
+      float z[L::V], pi[L::V];
 #pragma unroll
-      for (int v = 1; v < L::V; ++v) m = fmaxf(m, zn[ps][v]);
+      for (int v = 0; v < L::V; ++v) z[v] = zn[ps % NZ][v];
+      if constexpr (MFMA) {
+        if (ps + 1 < NP) fetch_pass(tile0, ps + 1);
+      }
+      float m = z[0];
+#pragma unroll
+      for (int v = 1; v < L::V; ++v) m = fmaxf(m, z[v]);
       m = group_max<L::G>(m);
       float sum = 0;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((zn[ps][v] - m) * LOG2E); sum += pi[v]; }   // 0 on masked slots
+      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((z[v] - m) * LOG2E); sum += pi[v]; }   // 0 on masked slots
       sum = group_sum<L::G>(sum);
       const float inv = fast_rcp(sum);
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        zkeep[ps][v] = zn[ps][v];
+        if constexpr (!MFMA) zkeep[ps][v] = z[v];
         const int c = L::cls(g, v);
         if (valid(c)) s_pi[(size_t)tok * LDK + c] = live ? pi[v] * inv : 0.0f;
       }
@@ -377,9 +403,15 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       if constexpr (MODE == DENSE_LOSS) {
         float zx0 = 0;
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0c[ps]) ? zn[ps][v] : 0.0f;
+        for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0c[ps]) ? z[v] : 0.0f;
         zx0 = group_sum<L::G>(zx0);
         cekeep[ps] = fmaf(fast_log2(sum), LN2, m) - zx0;
+      }
+      if constexpr (MFMA) {
+        if (g == 0) {
+          s_toki[2 * tok] = x0c[ps]; s_toki[2 * tok + 1] = xtc[ps];
+          s_tokf[3 * tok] = cekeep[ps]; s_tokf[3 * tok + 1] = m; s_tokf[3 * tok + 2] = inv;
+        }
       }
       if constexpr (MODE == DENSE_SAMPLE) {
         if (e.probs && live) {
@@ -389,18 +421,21 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
           store_slots<L>(e.probs + n * K, g, K, pi);
         }
       }
+      if constexpr (MFMA) __builtin_amdgcn_sched_barrier(0);   // keeps the next passes' loads from being hoisted (registers)
     }
     // table rows of the epilogue: column x_t of Q_t and (loss only) row x0 of Qbar_{t-1}; those of the first
     // pass are requested here, ahead of the contraction, the others one pass ahead
-    float f1n[NP][L::V], f2n[NP][L::V];
+    float f1n[NZ][L::V], f2n[NZ][L::V];
+    auto tok_x0 = [&](int ps) { return MFMA ? s_toki[2 * (ps * C::TPP + slot)] : x0c[ps]; };
+    auto tok_xt = [&](int ps) { return MFMA ? s_toki[2 * (ps * C::TPP + slot) + 1] : xtc[ps]; };
     auto gather = [&](int ps) {
-      load_slots<L>(a.tb.qoneT + ((size_t)t * K + xtc[ps]) * K, g, K, 0.0f, f1n[ps]);
+      load_slots<L>(a.tb.qoneT + ((size_t)t * K + tok_xt(ps)) * K, g, K, 0.0f, f1n[ps % NZ]);
       if constexpr (MODE == DENSE_LOSS)
-        load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + x0c[ps]) * K, g, K, 0.0f, f2n[ps]);
+        load_slots<L>(a.tb.qbar + ((size_t)(t - 1) * K + tok_x0(ps)) * K, g, K, 0.0f, f2n[ps % NZ]);
     };
-    if (need_post) gather(0);
+    if (!MFMA && need_post) gather(0);
     const bool more = tile0 + C::TM < p1;
-    if (!GRAD && more) fetch_tile(tile0 + C::TM);
+    if (!MFMA && !GRAD && more) fetch_tile(tile0 + C::TM);
     __syncthreads();
     D3PM_PHASE(1);
     // ---- phase 2: f2 = pi @ Qbar_{t-1}
@@ -411,6 +446,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
     __syncthreads();
     D3PM_PHASE(2);
     // ---- phase 3: per-token epilogue
+    if (MFMA && need_post) gather(0);
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int tok = ps * C::TPP + slot;
@@ -418,6 +454,9 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       const bool live = pos < p1;
       const long n = (long)b * a.npos + (live ? pos : tile0);
       float f2e[L::V];
+      if constexpr (MFMA && MODE != DENSE_LOSS) {
+        if (t == 0) load_slots<L>(e.logits + n * e.ld, g, K, -INFINITY, zkeep[0]);    // rare: 1 / T of the workgroups
+      }
       if (need_post) {
         if (ps + 1 < NP) gather(ps + 1);
 #pragma unroll
@@ -426,19 +465,22 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
           f2e[v] = (valid(c) ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
         }
       }
+      if constexpr (MFMA && !GRAD) {
+        if (ps == NP - 1 && more) fetch_tile(tile0 + C::TM);
+      }
       if constexpr (MODE == DENSE_LOSS) {
         // kl = sum_j q_j log(q_j / p_j) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of
         // Qbar_{t-1} + eps, f2 = pi Qbar_{t-1} + eps): the reference's softmax(log a + log .) pairs folded, one
         // log per class (of a ratio close to one where q is large).
-        const float ce = cekeep[ps];
+        const float ce = MFMA ? s_tokf[3 * tok] : cekeep[ps];
         float vb = ce;
         if (need_post) {
           float av[L::V], bv[L::V], zm = 0, zt = 0;
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
             const bool ok = valid(L::cls(g, v));
-            av[v] = ok ? f1n[ps][v] + eps : 0.0f;
-            bv[v] = f2n[ps][v] + eps;
+            av[v] = ok ? f1n[ps % NZ][v] + eps : 0.0f;
+            bv[v] = f2n[ps % NZ][v] + eps;
             zm = fmaf(av[v], f2e[v], zm);
             zt = fmaf(av[v], bv[v], zt);
           }
@@ -463,43 +505,58 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         float lm[L::V];
         if (need_post) {
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) lm[v] = logf(f1n[ps][v] + eps) + logf(f2e[v]);
+          for (int v = 0; v < L::V; ++v) {
+            // noise drawn on the device: no host computation to match bit for bit, hardware log2 of the product
+            if constexpr (MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX) lm[v] = fast_log2((f1n[ps % NZ][v] + eps) * f2e[v]) * LN2;
+            else lm[v] = logf(f1n[ps % NZ][v] + eps) + logf(f2e[v]);
+          }
         }
         if constexpr (MODE == DENSE_POST) {
           float r[L::V];
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps][v] : lm[v];
+          for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps % NKEEP][v] : lm[v];
           if (live) store_slots<L>(e.out + n * K, g, K, r);
         } else {   // DENSE_SAMPLE
           float best = -INFINITY;
           int besti = 0x7fffffff;
           float u[L::V];
-          if (t > 0) {
-            if constexpr (NOISE == D3PM_NOISE_PHILOX) {
-#pragma unroll
-              for (int h = 0; h < L::V / 4; ++h) {
-                const U4 r = philox4x32_10(((uint64_t)n * L::G + g) * (L::V / 4) + h, e.offset, e.seed);
-                u[4 * h + 0] = u01(r.x); u[4 * h + 1] = u01(r.y); u[4 * h + 2] = u01(r.z); u[4 * h + 3] = u01(r.w);
-              }
-            } else {
-              load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
-            }
+          if constexpr (NOISE != D3PM_NOISE_PHILOX) {
+            if (t > 0) load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
           }
+          // four classes at a time: one Philox call feeds them, and its words die before the next call
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
-            float val;
-            if (t == 0) val = zkeep[ps][v];
-            else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]));
-            if (valid(c) && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+          for (int h = 0; h < (L::V + 3) / 4; ++h) {
+            if constexpr (NOISE == D3PM_NOISE_PHILOX) {
+              if (t > 0) {
+                const U4 r = philox4x32_10(((uint64_t)n * L::G + g) * ((L::V + 3) / 4) + h, e.offset, e.seed);
+                const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (4 * h + j < L::V) u[4 * h + j] = u01(rr[j]);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int v = 4 * h + j;
+              if (v >= L::V) continue;
+              const int c = L::cls(g, v);
+              float val;
+              if (t == 0) val = zkeep[ps % NKEEP][v];
+              else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v]
+                              : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v])));
+              if (valid(c) && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
+            }
+            if constexpr (MFMA && NOISE == D3PM_NOISE_PHILOX) __builtin_amdgcn_sched_barrier(0);
           }
           group_argmax<L::G>(best, besti);
           if (g == 0 && live) e.sample[n] = besti;
         }
       }
+      if constexpr (MFMA) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MODE == DENSE_LOSS && GRAD) {
-      if (more) fetch_tile(tile0 + C::TM);
+      if constexpr (MFMA) fetch_row(tile0, 0);
+      else if (more) fetch_tile(tile0 + C::TM);
       __syncthreads();
       D3PM_PHASE(3);
       // ---- phase 4: d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T
@@ -514,14 +571,25 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       for (int ps = 0; ps < NP; ++ps) {
         const int tok = ps * C::TPP + slot;
         const long pos = tile0 + tok;
+        const int x0 = tok_x0(ps);
+        float pi[L::V], gz[L::V];
+        if constexpr (MFMA) {
+          // softmax again from the re-read row (same max and 1 / sum: bit-identical to phase 1); the row after it,
+          // or the next tile's first pass, is requested meanwhile
+          const float m = s_tokf[3 * tok + 1], inv = s_tokf[3 * tok + 2];
+#pragma unroll
+          for (int v = 0; v < L::V; ++v) pi[v] = fast_exp2((zn[ps % NZ][v] - m) * LOG2E) * inv;
+          if (ps + 1 < NP) fetch_row(tile0, ps + 1);
+          else if (more) fetch_tile(tile0 + C::TM);
+        }
         if (pos >= p1) continue;     // whole lane groups leave together
         const long n = (long)b * a.npos + pos;
-        const int x0 = x0c[ps];
-        float pi[L::V], gz[L::V];
+        if constexpr (!MFMA) {
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          const int c = L::cls(g, v);
-          pi[v] = valid(c) ? s_pi[(size_t)tok * LDK + c] : 0.0f;
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            pi[v] = valid(c) ? s_pi[(size_t)tok * LDK + c] : 0.0f;
+          }
         }
         if (need_post) {
           float gp[L::V], dot = 0;
@@ -542,6 +610,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         }
         store_slots<L>(e.dlogits + n * e.ld, g, K, gz);
         if (!L::VEC && e.ld > K) zero_tail<L>(e.dlogits + n * e.ld, g, K, e.ld);
+        if constexpr (MFMA) __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();   // LDS tiles are reused by the next tile
@@ -600,7 +669,7 @@ template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
 static int launch_tile(const d3pm_tables_f32* tb, const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   using C = DenseCfg<L, MFMA>;
   static const size_t lds_pad = getenv("D3PM_DENSE_LDS_PAD") ? (size_t)atoi(getenv("D3PM_DENSE_LDS_PAD")) : 0;   // tuning aid: lowers occupancy
-  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * ((GRAD && !MFMA) ? 3 : 2) + lds_pad;
+  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * (MFMA ? 1 : (GRAD ? 3 : 2)) + lds_pad;
   auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA>;
   if (sh > 48 * 1024) {
     hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

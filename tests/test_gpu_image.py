@@ -188,6 +188,51 @@ def test_seeded_against_oracle_odd_shapes(pkg):
             close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
 
 
+@pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
+def test_k256_matrix_core_tiles_against_oracle(pkg, B, L):
+    """K = 256 runs its contractions on the matrix cores in tiles of 64 tokens:
+    several tiles per workgroup, a partial last tile, a single-token tail, a t = 0
+    batch element, more batch elements than one round of the XCD mapping."""
+    K, T = 256, 20
+    betas = pkg.generate_betas(1e-3, 0.3, T, "linear")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="gaussian", num_bits=8, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.01, device=DEV)
+    p = im.build_process(betas, "gaussian", 8, None, hybrid_coeff=0.01)
+    gen = torch.Generator().manual_seed(1000 * B + L)
+    x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen)
+    t = torch.randint(1, T, (B,), generator=gen, dtype=torch.int32)
+    t[0] = 0
+    noise = torch.rand(B, L, 1, 1, K, generator=gen)
+    logits = 3 * torch.randn(B, L, 1, 1, K, generator=gen)
+    xt_ref = im.forward_sample(p, x0, t, noise)
+    for lt in ("hybrid", "kl", "cross_entropy_x_start"):
+        p.loss_type = d.loss_type = lt
+        lg_ref = logits.clone().requires_grad_(True)
+        loss_ref = im.losses_given_xt(p, lg_ref, x0, xt_ref, t)
+        w = torch.linspace(0.5, 1.5, B)
+        (loss_ref * w).sum().backward()
+        lg = logits.to(DEV).requires_grad_(True)
+        loss = d.training_losses(lambda x, tt: lg, x_start=x0.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+        (loss * w.to(DEV)).sum().backward()
+        close(loss, loss_ref.detach().numpy(), atol=LOSS_ATOL, what=f"loss {lt}")
+        ref = lg_ref.grad.numpy()
+        close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {lt}")
+    d.loss_type = "hybrid"
+    post = d.q_posterior_logits(logits.to(DEV), xt_ref.to(DEV), t.to(DEV), x_start_logits=True)
+    close(post, im.posterior_logits(p, logits, xt_ref, t, True).numpy(), atol=1e-5, what="posterior logits")
+    # device-noise sampling: the same generator state gives the same tokens, t = 0 rows are the argmax of the
+    # logits, and the sampled classes follow the posterior (every sampled class has non-negligible probability)
+    out = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        out.append(d.p_sample(lambda x, tt: logits.to(DEV), x=xt_ref.to(DEV), t=t.to(DEV))[0])
+    assert torch.equal(out[0], out[1])
+    assert torch.equal(out[0][0].cpu(), logits[0].argmax(-1))
+    lp = torch.log_softmax(post.cpu(), -1).gather(-1, out[0].cpu()[..., None])[..., 0]
+    assert float(lp[1:].min()) > -25.0 if B > 1 else True
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--L", type=int, default=512)
     ap.add_argument("--bits", type=int, default=5)
     ap.add_argument("--kind", default="uniform")
+    ap.add_argument("--same-t", action="store_true", help="one timestep for the whole batch (tables stay in L2)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, L, K = a.B, a.L, 2 ** a.bits
@@ -46,6 +47,8 @@ def main():
     tb = d.tables()
     x0 = torch.randint(0, K, (B, L), device=dev)
     t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+    if a.same_t:
+        t = torch.full_like(t, T // 2)
     logits = torch.randn(B, L, K, device=dev)
     x_t = d.q_sample(x0, t)
     dl = torch.empty_like(logits)
