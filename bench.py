@@ -269,15 +269,15 @@ def main():
             check(lib.d3pm_hybrid_loss(tbi.desc(), ptr(lgi), KI, ptr(x0i), 8, ptr(xti), 8, ptr(ti), 4, BI, LI,
                                        LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dli), None, None, 0, ptr(wsi),
                                        wsbi, sp))
-        for _ in range(3):
+        for _ in range(20):
             dense_only()
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(20):
+        for _ in range(100):
             dense_only()
         e1.record()
         torch.cuda.synchronize()
-        dms = e0.elapsed_time(e1) / 20
+        dms = e0.elapsed_time(e1) / 100
         tfl = 4.0 * KI * KI * BI * LI / (dms * 1e-3) / 1e12
         dense = {"workload": "image D3PM B=128 32x32x1 K=256 T=1000 Gaussian Q, fused loss fwd+bwd to dlogits",
                  "kernel_ms": dms, "tokens_per_s": BI * LI / (dms * 1e-3),

@@ -55,6 +55,8 @@ SIGNATURES = {
     "d3pm_scale_rows": (_I, [_P, _P, _F, _I, _L, _P]),
     "d3pm_p_sample": (_I, [_T32, _P, _L, _P, _I, _P, _I, _I, _L, _P, _I, _U64, _U64, _P, _P, _P, _P]),
     "d3pm_prior_bpd": (_I, [_T32, _P, _I, _I, _L, _I, _P, _P, _SZ, _P]),
+    "d3pm_logistic_logits": (_I, [_P, _P, _P, _L, _I, _F, _P, _P]),
+    "d3pm_logistic_logits_backward": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "d3pm_corrupt": (_I, [_T64, _P, _P, _I, _L, _P, _U64, _U64, _P, _P, _P]),
     "d3pm_lvb_loss_workspace": (_SZ, [_I, _L, _I]),
     "d3pm_lvb_loss": (_I, [_T64, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _D, _P, _P, _P, _SZ, _P]),

@@ -57,6 +57,34 @@ def _philox_ticket(device) -> tuple:
     return seed & 0xFFFFFFFFFFFFFFFF, off
 
 
+class _LogisticLogits(torch.autograd.Function):
+    """Bin logits of the discretised logistic and their gradient to (loc,
+    log_scale): one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, loc, log_scale, centers, eps):
+        K = centers.numel()
+        loc_c, ls_c = loc.contiguous().float(), log_scale.contiguous().float()
+        _lib.require_device(loc_c, ls_c, centers)
+        out = torch.empty(loc.shape + (K,), dtype=torch.float32, device=loc.device)
+        with torch.cuda.device(loc.device):
+            check(lib.d3pm_logistic_logits(ptr(loc_c), ptr(ls_c), ptr(centers), loc_c.numel(), K, eps, ptr(out),
+                                           stream_ptr()))
+        ctx.save_for_backward(loc_c, ls_c, centers)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        loc, ls, centers = ctx.saved_tensors
+        g = grad.contiguous().float()
+        dloc, dls = torch.empty_like(loc), torch.empty_like(ls)
+        with torch.cuda.device(loc.device):
+            check(lib.d3pm_logistic_logits_backward(ptr(loc), ptr(ls), ptr(centers), ptr(g), loc.numel(),
+                                                    centers.numel(), ctx.eps, ptr(dloc), ptr(dls), stream_ptr()))
+        return dloc, dls, None, None
+
+
 class _FusedLoss(torch.autograd.Function):
     """loss[B] = (vb | ce | vb + lambda*ce) of one batch; d loss / d logits is
     produced by the same kernel with `baked` as upstream gradient and rescaled
@@ -204,9 +232,10 @@ class DiscreteDiffusion:
 
     def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform", rng=None):
         """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64.
-        ``rng=(seed, counter)`` with ``counter`` a one-element int64 device
-        tensor selects the Philox stream explicitly (for HIP-graph capture,
-        where the caller advances ``counter`` inside the graph)."""
+        ``rng=(seed, counter[, offset])`` with ``counter`` a one-element int64
+        device tensor selects the Philox stream explicitly: stream offset =
+        ``offset`` + the counter's value at execution time (for HIP-graph
+        capture, where the counter is advanced between or inside replays)."""
         x = _as_tokens(x_start)
         _lib.require_device(x)
         tb = self.tables()
@@ -218,6 +247,7 @@ class DiscreteDiffusion:
             kind = _lib.NOISE_PHILOX
             if rng is not None:
                 seed, off_dev = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, rng[1]
+                off = int(rng[2]) if len(rng) > 2 else 0
                 assert off_dev.dtype == torch.int64 and off_dev.is_cuda
             else:
                 seed, off = _philox_ticket(x.device)
@@ -233,15 +263,15 @@ class DiscreteDiffusion:
 
     # ------------------------------------------------------------------ posterior
     def _get_logits_from_logistic_pars(self, loc, log_scale):
-        """Logits of a discretised logistic (:288-309); elementwise tensor ops."""
-        loc, log_scale = loc.unsqueeze(-1), log_scale.unsqueeze(-1)
-        inv_scale = torch.exp(-(log_scale - 2.0))
-        K = self.num_pixel_vals
-        width = 2.0 / (K - 1.0)
-        centers = torch.linspace(-1.0, 1.0, K, device=loc.device).view(*([1] * (loc.dim() - 1)), K) - loc
-        lo = F.logsigmoid(inv_scale * (centers - 0.5 * width))
-        hi = F.logsigmoid(inv_scale * (centers + 0.5 * width))
-        return utils.log_min_exp(hi, lo, self.eps)
+        """Logits of a discretised logistic (:288-309, utils.log_min_exp :15-18);
+        differentiable with respect to both parameters."""
+        assert loc.shape == log_scale.shape, (loc.shape, log_scale.shape)
+        centers = getattr(self, "_bin_centers", None)
+        if centers is None or centers.device != loc.device:
+            # the reference's own expression for the centres (evaluated on the host: one rounding behaviour)
+            centers = self._bin_centers = torch.linspace(start=-1.0, end=1.0,
+                                                         steps=self.num_pixel_vals).to(loc.device)
+        return _LogisticLogits.apply(loc, log_scale, centers, float(self.eps))
 
     def q_posterior_logits(self, x_start, x_t, t, x_start_logits):
         """Logits of q(x_{t-1} | x_t, x_start) (:312-336)."""
@@ -474,13 +504,21 @@ class DiscreteDiffusion:
         return one
 
     @torch.no_grad()
-    def calc_bpd_loop(self, model_fn, *, x_start):
-        """Variational bound over all timesteps (:584-629)."""
+    def calc_bpd_loop(self, model_fn, *, x_start, noise=None, rng=None):
+        """Variational bound over all timesteps (:584-629): x_t ~ q(x_t | x_0) and
+        the bound's term at every t, plus the prior term.  ``noise`` (optional,
+        indexable by t, each ``x_start.shape + (K,)`` uniform) replaces the
+        reference's per-step ``torch.rand`` (:611); without it the corruption
+        draws Philox noise on the device (``rng=(seed, counter)`` as in q_sample:
+        step t uses stream offset 4 t + counter, which makes the whole sweep
+        capturable, see ``GraphedBpdSweep``)."""
         B = x_start.shape[0]
         vb_tb = torch.empty((self.num_timesteps, B), dtype=torch.float32, device=self.device)
+        ts = torch.arange(self.num_timesteps, dtype=torch.int32, device=self.device)[:, None].expand(-1, B).contiguous()
         for step in range(self.num_timesteps):
-            t = torch.full((B,), step, dtype=torch.int32, device=self.device)
-            x_t = self.q_sample(x_start=x_start, t=t)
+            t = ts[step]
+            x_t = self.q_sample(x_start=x_start, t=t, noise=None if noise is None else noise[step],
+                                rng=None if rng is None else (rng[0], rng[1], 4 * step))
             vb_tb[step], _ = self.vb_terms_bpd(model_fn=model_fn, x_start=x_start, x_t=x_t, t=t)
         prior = self.prior_bpd(x_start=x_start)
         total = vb_tb.sum(dim=0) + prior

@@ -143,3 +143,37 @@ class GraphedReverseSampler:
         self.counter.add_(self.stride)
         self.graph.replay()
         return self.out
+
+
+class GraphedBpdSweep:
+    """``DiscreteDiffusion.calc_bpd_loop`` -- corruption, denoiser and bound term at
+    every timestep, then the prior term and the total -- for a fixed ``x_start``
+    buffer, captured into one HIP graph.  Eagerly the sweep is T rounds of a few
+    short launches each and is bound by the host; the replay runs them back to
+    back.  Every replay corrupts with fresh noise (device Philox counter, advanced
+    by 4 T per call).  ``replay()`` returns the static result dict of
+    ``calc_bpd_loop``; copy new data into ``x_start`` between calls."""
+
+    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0):
+        self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
+        self.seed = int(seed)
+        dev = x_start.device
+        diffusion.tables()                                   # set-up syncs are not capturable
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.stride = 4 * diffusion.num_timesteps
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():       # one untimed step of each kind outside the capture
+            t0 = torch.zeros(x_start.shape[0], dtype=torch.int32, device=dev)
+            x_t = diffusion.q_sample(x_start, t0, rng=(self.seed, self.counter))
+            diffusion.vb_terms_bpd(model_fn, x_start=x_start, x_t=x_t, t=t0)
+            diffusion.prior_bpd(x_start)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = diffusion.calc_bpd_loop(model_fn, x_start=x_start, rng=(self.seed, self.counter))
+
+    def replay(self) -> dict:
+        self.counter.add_(self.stride)
+        self.graph.replay()
+        return self.out

@@ -194,6 +194,22 @@ int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const
 int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
                    int absorbing, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* _get_logits_from_logistic_pars (d3pm/diffusion_discrete.py:288-309) with
+ * utils.log_min_exp (d3pm/utils.py:15-18): the model_output == 'logistic_pars'
+ * head.  logits[n,k] = hi + log1p(-exp(lo - hi) + eps) with
+ * lo/hi = logsigmoid(exp(2 - log_scale[n]) * (centers[k] - loc[n] -/+ 1/(K-1))).
+ *   loc, log_scale float32 [N] (N = B*npos); centers float32 [K], the reference's
+ *   torch.linspace(-1, 1, K); logits float32 [N,K]. */
+int d3pm_logistic_logits(const float* loc, const float* log_scale, const float* centers, long N, int K,
+                         float eps, float* logits, void* stream);
+
+/* Gradient of the above (what autograd derives from :288-309 in the
+ * reference): dloc[n] = sum_k dlogits[n,k] * d logits[n,k] / d loc[n], likewise
+ * dlog_scale; float32 [N]. */
+int d3pm_logistic_logits_backward(const float* loc, const float* log_scale, const float* centers,
+                                  const float* dlogits, long N, int K, float eps, float* dloc,
+                                  float* dlog_scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * Protein-style process (protein_generation/)
  * --------------------------------------------------------------------- */

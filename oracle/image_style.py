@@ -243,6 +243,22 @@ def log_min_exp(a: torch.Tensor, b: torch.Tensor, eps: float = EPS) -> torch.Ten
     return a + torch.log1p(-torch.exp(b - a) + eps)
 
 
+def logits_from_logistic_pars(loc: torch.Tensor, log_scale: torch.Tensor, K: int, eps: float = EPS) -> torch.Tensor:
+    """``_get_logits_from_logistic_pars`` (:288-309): bin logits of a logistic
+    with location ``loc`` and scale ``exp(log_scale - 2)`` over K bins centred on
+    linspace(-1, 1, K)."""
+    loc, log_scale = loc.unsqueeze(-1), log_scale.unsqueeze(-1)
+    inv_scale = torch.exp(-(log_scale - 2.0))
+    width = 2.0 / (K - 1.0)
+    centers = torch.linspace(start=-1.0, end=1.0, steps=K)
+    for _ in range(loc.ndim - 1):
+        centers = centers.unsqueeze(0)
+    centers = centers - loc
+    lo = torch.nn.functional.logsigmoid(inv_scale * (centers - 0.5 * width))
+    hi = torch.nn.functional.logsigmoid(inv_scale * (centers + 0.5 * width))
+    return log_min_exp(hi, lo, eps)
+
+
 # --------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------
@@ -297,3 +313,18 @@ def training_step(p: Process, model_fn: Callable, x0: torch.Tensor, t: torch.Ten
     (losses[B], x_t)."""
     x_t = forward_sample(p, x0, t, noise)
     return losses_given_xt(p, model_fn(x_t, t), x0, x_t, t), x_t
+
+
+def bpd_sweep(p: Process, model_fn: Callable, x0: torch.Tensor, noises) -> dict:
+    """``calc_bpd_loop`` (:584-629): the variational-bound term of every timestep
+    (x_t drawn from q with ``noises[t]``, the uniform tensor the reference draws at
+    :611) plus the prior term.  Returns total [B], vbterms [B, T], prior [B]."""
+    B = x0.shape[0]
+    vb_tb = torch.empty((p.T, B), dtype=torch.float32)
+    with torch.no_grad():
+        for step in range(p.T):
+            t = torch.full((B,), step, dtype=torch.int32)
+            x_t = forward_sample(p, x0, t, noises[step])
+            vb_tb[step] = vb_terms(p, model_fn(x_t, t), x0, x_t, t)[0]
+        prior = prior_term(p, x0)
+    return {"total": vb_tb.sum(dim=0) + prior, "vbterms": vb_tb.T, "prior": prior}

@@ -233,6 +233,133 @@ def test_k256_matrix_core_tiles_against_oracle(pkg, B, L):
     assert float(lp[1:].min()) > -25.0 if B > 1 else True
 
 
+def _logistic_f64(loc, ls, K, eps=1e-6):
+    """The head's formula in float64 (centres as the float32 linspace the reference uses)."""
+    loc, ls = loc.double().unsqueeze(-1), ls.double().unsqueeze(-1)
+    s = torch.exp(-(ls - 2.0))
+    c = torch.linspace(-1.0, 1.0, K).double() - loc
+    hw = float(np.float32(0.5 * (2.0 / (K - 1.0))))
+    lo = torch.nn.functional.logsigmoid(s * (c - hw))
+    hi = torch.nn.functional.logsigmoid(s * (c + hw))
+    return hi + torch.log1p(-torch.exp(lo - hi) + float(np.float32(eps)))
+
+
+def _logistic_condition(loc, ls, K, eps=1e-6):
+    """1 + eps - exp(lo - hi), the argument of the final logarithm: one float32
+    rounding of exp(lo - hi) (6e-8) moves the logit by 6e-8 / this."""
+    loc, ls = loc.double().unsqueeze(-1), ls.double().unsqueeze(-1)
+    s = torch.exp(-(ls - 2.0))
+    c = torch.linspace(-1.0, 1.0, K).double() - loc
+    hw = float(np.float32(0.5 * (2.0 / (K - 1.0))))
+    lo = torch.nn.functional.logsigmoid(s * (c - hw))
+    hi = torch.nn.functional.logsigmoid(s * (c + hw))
+    return (1.0 + eps - torch.exp(lo - hi)).numpy()
+
+
+def test_logistic_head_golden(pkg):
+    """model_output == 'logistic_pars': bin logits and their gradient against the
+    reference's recorded float32 values.  Far-tail bins are rounding-dominated in
+    the reference itself (log of 1 + eps - exp(lo - hi) with lo - hi -> 0), so the
+    bar is: no further from the float64 value of the formula than 3x the
+    reference's own float32 result is, plus 1e-6 relative."""
+    g = golden("image_misc")
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, 20, "jsd"), transition_mat_type="uniform", num_bits=4,
+                              transition_bands=None, model_prediction="x_start", model_output="logistic_pars",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    loc = T_(g["logistic_loc"]).requires_grad_(True)
+    ls = T_(g["logistic_log_scale"]).requires_grad_(True)
+    out = d._get_logits_from_logistic_pars(loc, ls)
+    assert out.shape == loc.shape + (16,) and out.dtype == torch.float32
+    (out * T_(g["logistic_w"])).sum().backward()
+    l64, s64 = torch.from_numpy(g["logistic_loc"]).double().requires_grad_(True), \
+        torch.from_numpy(g["logistic_log_scale"]).double().requires_grad_(True)
+    o64 = _logistic_f64(l64, s64, 16)
+    (o64 * torch.from_numpy(g["logistic_w"]).double()).sum().backward()
+    for mine, ref, exact, what in ((out.detach(), g["logistic_logits"], o64.detach(), "logits"),
+                                   (loc.grad, g["logistic_grad_loc"], l64.grad, "d loc"),
+                                   (ls.grad, g["logistic_grad_log_scale"], s64.grad, "d log_scale")):
+        exact = exact.numpy()
+        err_ref = np.abs(ref - exact)
+        err = np.abs(mine.cpu().numpy() - exact)
+        bound = 3 * err_ref.max() + 1e-6 * np.abs(exact).max()
+        assert err.max() <= bound, f"{what}: {err.max():.3e} from float64, reference {err_ref.max():.3e}"
+    # and element by element, with the rounding sensitivity of each bin spelled out
+    cond = _logistic_condition(torch.from_numpy(g["logistic_loc"]), torch.from_numpy(g["logistic_log_scale"]), 16)
+    diff = np.abs(out.detach().cpu().numpy() - g["logistic_logits"])
+    assert (diff <= 2e-5 * np.abs(g["logistic_logits"]) + 2e-6 + 4e-7 / cond).all(), diff.max()
+    assert (cond > 1e-2).mean() > 0.5        # most bins are held to 4e-5 or better
+
+
+def test_logistic_head_against_oracle_k256(pkg):
+    """K = 256 (four bins per lane), odd position count, wide range of scales."""
+    gen = torch.Generator().manual_seed(31)
+    loc = torch.rand(3, 7, 5, generator=gen) * 2.4 - 1.2
+    ls = torch.randn(3, 7, 5, generator=gen)
+    w = torch.randn(3, 7, 5, 256, generator=gen)
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, 20, "jsd"), transition_mat_type="uniform", num_bits=8,
+                              transition_bands=None, model_prediction="x_start", model_output="logistic_pars",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    lr, sr = loc.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    ref = im.logits_from_logistic_pars(lr, sr, 256)
+    (ref * w).sum().backward()
+    l64, s64 = loc.double().requires_grad_(True), ls.double().requires_grad_(True)
+    o64 = _logistic_f64(l64, s64, 256)
+    (o64 * w.double()).sum().backward()
+    lg, sg = loc.to(DEV).requires_grad_(True), ls.to(DEV).requires_grad_(True)
+    out = d._get_logits_from_logistic_pars(lg, sg)
+    (out * w.to(DEV)).sum().backward()
+    for mine, r, exact, what in ((out.detach(), ref.detach(), o64.detach(), "logits"), (lg.grad, lr.grad, l64.grad, "d loc"),
+                                 (sg.grad, sr.grad, s64.grad, "d log_scale")):
+        exact = exact.numpy()
+        err_ref, err = np.abs(r.numpy() - exact), np.abs(mine.cpu().numpy() - exact)
+        assert err.max() <= 3 * err_ref.max() + 1e-6 * np.abs(exact).max(), (what, err.max(), err_ref.max())
+    # empty input
+    e = d._get_logits_from_logistic_pars(torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, device=DEV))
+    assert e.shape == (0, 4, 256)
+
+
+def test_calc_bpd_loop_golden(pkg):
+    """calc_bpd_loop with the logistic_pars head, replayed on the reference's
+    per-step noise: every timestep's bound term, the prior term and the total."""
+    g = golden("image_bpd_loop")
+    d = pkg.DiscreteDiffusion(betas=torch.from_numpy(g["betas"]), transition_mat_type="gaussian", num_bits=4,
+                              transition_bands=None, model_prediction="x_start", model_output="logistic_pars",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    loc, ls = T_(g["loc"]), T_(g["log_scale"])
+    res = d.calc_bpd_loop(lambda x, t: (loc, ls), x_start=T_(g["x0"]), noise=T_(g["noises"]))
+    assert res["vbterms"].shape == (3, 40)
+    close(res["vbterms"], g["vbterms"], rtol=1e-5, atol=LOSS_ATOL, what="vbterms")
+    close(res["prior"], g["prior"], rtol=1e-4, atol=LOSS_ATOL, what="prior")
+    close(res["total"], g["total"], rtol=1e-5, atol=40 * LOSS_ATOL, what="total")
+    # device noise: a different corruption draw, same expectation within Monte-Carlo spread of 10 positions
+    res2 = d.calc_bpd_loop(lambda x, t: (loc, ls), x_start=T_(g["x0"]))
+    assert torch.isfinite(res2["total"]).all() and res2["prior"].allclose(res["prior"])
+
+
+def test_graphed_bpd_sweep(pkg):
+    """The whole calc_bpd_loop sweep replayed as one HIP graph equals the eager
+    sweep on the same Philox stream; a second replay draws different corruption."""
+    from d3pm_amd.graphs import GraphedBpdSweep
+    T, K, B = 30, 32, 5
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randint(0, K, (B, 40, 1, 1), generator=gen).to(DEV)
+    emb = torch.randn(K, K, generator=gen).to(DEV)
+    temb = torch.randn(T, K, generator=gen).to(DEV)
+    model = lambda x, t: emb[x] + temb[t.long()][:, None, None, None, :]      # depends on x_t and t
+    sweep = GraphedBpdSweep(d, model, x0, seed=11)
+    r1 = {k: v.clone() for k, v in sweep.replay().items()}
+    counter = torch.full((1,), 4 * T, dtype=torch.int64, device=DEV)           # the counter's value in that replay
+    eager = d.calc_bpd_loop(model, x_start=x0, rng=(11, counter))
+    for k in ("total", "vbterms", "prior"):
+        assert torch.equal(r1[k], eager[k]), k
+    r2 = sweep.replay()
+    assert not torch.equal(r1["vbterms"], r2["vbterms"]) and torch.equal(r1["prior"], r2["prior"])
+    assert r2["vbterms"].shape == (B, T) and torch.isfinite(r2["total"]).all()
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,

@@ -241,3 +241,21 @@ def test_protein_mutant_scores(tmp_path):
                              lambda i: g["orders"][i], lambda i, j: tmid[i * nb + j // mb],
                              lambda i, j, h: Em[(i * nb + j // mb) * 3 + h])
     np.testing.assert_allclose(delta, g["delta_elbos"], rtol=1e-6, atol=1e-7)
+
+
+def test_logistic_head_and_bpd_loop():
+    """The discretised-logistic head (bit for bit, and its autograd gradient) and
+    calc_bpd_loop replayed on the recorded per-step noise."""
+    g = golden("image_misc")
+    loc, ls = T_(g["logistic_loc"]).requires_grad_(True), T_(g["logistic_log_scale"]).requires_grad_(True)
+    out = im.logits_from_logistic_pars(loc, ls, 16)
+    np.testing.assert_array_equal(out.detach().numpy(), g["logistic_logits"])
+    (out * T_(g["logistic_w"])).sum().backward()
+    np.testing.assert_array_equal(loc.grad.numpy(), g["logistic_grad_loc"])
+    np.testing.assert_array_equal(ls.grad.numpy(), g["logistic_grad_log_scale"])
+    g = golden("image_bpd_loop")
+    p = im.build_process(T_(g["betas"]), "gaussian", 4, None, hybrid_coeff=0.001)
+    logits = im.logits_from_logistic_pars(T_(g["loc"]), T_(g["log_scale"]), 16)
+    res = im.bpd_sweep(p, lambda x, t: logits, T_(g["x0"]), T_(g["noises"]))
+    for k in ("total", "vbterms", "prior"):
+        np.testing.assert_array_equal(res[k].numpy(), g[k])

@@ -83,8 +83,20 @@ def main():
     def f_noop():
         check(lib.d3pm_scale_rows(ptr(dl), ptr(up), 0.5, B, L * K, s))
 
+    loc = torch.rand(N, device=dev) * 2 - 1
+    lsc = torch.randn(N, device=dev) * 0.5
+    cen = torch.linspace(-1.0, 1.0, K).to(dev)
+    dloc, dlsc = torch.empty_like(loc), torch.empty_like(lsc)
+
+    def f_logistic():
+        check(lib.d3pm_logistic_logits(ptr(loc), ptr(lsc), ptr(cen), N, K, 1e-6, ptr(dl), s))
+
+    def f_logistic_bwd():
+        check(lib.d3pm_logistic_logits_backward(ptr(loc), ptr(lsc), ptr(cen), ptr(logits), N, K, 1e-6, ptr(dloc), ptr(dlsc), s))
+
     for name, fn, bytes_per_tok in (("hybrid_loss fwd+bwd", f_loss, 8 * K + 16), ("hybrid_loss fwd", f_loss_fwd, 4 * K + 16),
                                     ("q_sample philox", f_qs, 16), ("p_sample philox", f_ps, 4 * K + 16),
+                                    ("logistic head fwd", f_logistic, 4 * K + 8), ("logistic head bwd", f_logistic_bwd, 4 * K + 16),
                                     ("torch copy_ (reference stream)", f_copy, 8 * K),
                                     ("scale_rows early exit (launch floor)", f_noop, 0)):
         us = timeit(fn, a.reps)

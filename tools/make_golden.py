@@ -194,13 +194,34 @@ def part_image():
     log_scale = torch.randn(3, 4, 4, 1, generator=g) * 0.5
     d = make("uniform", 4, dd.generate_betas(0.0, 0.0, 20, "jsd"))
     d.device = "cpu"
+    # gradient of the logistic head as autograd derives it, under a fixed weighting of the logits
+    loc_g, ls_g = loc.clone().requires_grad_(True), log_scale.clone().requires_grad_(True)
+    w_log = torch.randn(3, 4, 4, 1, 16, generator=g)
+    (d._get_logits_from_logistic_pars(loc_g, ls_g) * w_log).sum().backward()
     save("image_misc",
          betas_linear=dd.generate_betas(1e-4, 0.02, 1000, "linear").numpy(),
          betas_cosine=dd.generate_betas(0.0, 0.0, 500, "cosine").numpy(),
          betas_jsd=dd.generate_betas(0.0, 0.0, 500, "jsd").numpy(),
          lme_a=a.numpy(), lme_b=b.numpy(), lme_out=ru.log_min_exp(a, b).numpy(),
          logistic_loc=loc.numpy(), logistic_log_scale=log_scale.numpy(),
-         logistic_logits=d._get_logits_from_logistic_pars(loc, log_scale).numpy())
+         logistic_logits=d._get_logits_from_logistic_pars(loc, log_scale).numpy(),
+         logistic_w=w_log.numpy(), logistic_grad_loc=loc_g.grad.numpy(), logistic_grad_log_scale=ls_g.grad.numpy())
+
+    # --- calc_bpd_loop with the logistic_pars head: gaussian K=16, T=40, frozen (loc, log_scale) -----------------
+    betas = dd.generate_betas(0.002, 0.3, 40, "linear")
+    d = dd.DiscreteDiffusion(betas=betas, transition_mat_type="gaussian", num_bits=4, transition_bands=None,
+                             model_prediction="x_start", model_output="logistic_pars", loss_type="hybrid",
+                             hybrid_coeff=0.001, device="cpu")
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randint(0, 16, (3, 5, 2, 1), generator=g, dtype=torch.int64)
+    loc = torch.rand(3, 5, 2, 1, generator=g) * 2 - 1
+    log_scale = torch.randn(3, 5, 2, 1, generator=g) * 0.5
+    torch.manual_seed(4242)
+    res = d.calc_bpd_loop(lambda x, tt: (loc, log_scale), x_start=x0)
+    torch.manual_seed(4242)      # the draws of :611, in order
+    noises = torch.stack([torch.rand(x0.shape + (16,)) for _ in range(40)])
+    save("image_bpd_loop", betas=betas.numpy(), x0=x0.numpy(), loc=loc.numpy(), log_scale=log_scale.numpy(),
+         noises=noises.numpy(), total=res["total"].numpy(), vbterms=res["vbterms"].numpy(), prior=res["prior"].numpy())
 
 
 # ---------------------------------------------------------------------------
