@@ -274,6 +274,10 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
 
 enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
 
+#ifndef D3PM_VALU_PRIO
+#define D3PM_VALU_PRIO 2     // wave priority (0..3) of the per-token phases on the matrix-core path
+#endif
+
 struct DenseExtra {
   int B;
   unsigned long long* rng_counter; unsigned long long rng_step;   // see LossOut
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
     for (int ps = 0; ps < (MFMA ? 1 : NP); ++ps) fetch_pass(tile, ps);
   };
   fetch_tile(chunk * a.chunk_pos);
+  if constexpr (MFMA) __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += C::TM) {
     // ---- phase 1: softmax of the tile's logits into LDS, CE term
     constexpr int NKEEP = MFMA ? 1 : NP;
@@ -440,8 +445,13 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
     D3PM_PHASE(1);
     // ---- phase 2: f2 = pi @ Qbar_{t-1}
     if (need_post) {
-      if constexpr (MFMA) tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
-      else tile_contract<L>(Qm, K, s_pi, s_f2);
+      if constexpr (MFMA) {
+        // the co-resident workgroup's per-token phase issues ahead of this stream of long matrix instructions,
+        // which loses next to nothing by it
+        __builtin_amdgcn_s_setprio(0);
+        tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
+        __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
+      } else tile_contract<L>(Qm, K, s_pi, s_f2);
     }
     __syncthreads();
     D3PM_PHASE(2);
@@ -561,8 +571,11 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       D3PM_PHASE(3);
       // ---- phase 4: d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T
       if (need_post) {
-        if constexpr (MFMA) tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
-        else tile_contract<L>(QmT, K, s_f2, s_gp);
+        if constexpr (MFMA) {
+          __builtin_amdgcn_s_setprio(0);
+          tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
+          __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
+        } else tile_contract<L>(QmT, K, s_f2, s_gp);
       }
       __syncthreads();
       D3PM_PHASE(4);
