@@ -293,7 +293,7 @@ struct DenseExtra {
 template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
 __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, DenseExtra e) {
   using C = DenseCfg<L, MFMA>;
-  extern __shared__ float lds[];
+  extern __shared__ __align__(16) float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
   // matrix-core path: per-token scalars (x0, x_t | CE term, softmax max, 1 / sum) live here between phases
   // instead of in registers, which are what limits two workgroups per CU
@@ -398,11 +398,21 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((z[v] - m) * LOG2E); sum += pi[v]; }   // 0 on masked slots
       sum = group_sum<L::G>(sum);
       const float inv = fast_rcp(sum);
+      if constexpr (L::VEC) {      // whole 16-byte pieces: ds_write_b128
+        float pn[L::V];
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) {
-        if constexpr (!MFMA) zkeep[ps][v] = z[v];
-        const int c = L::cls(g, v);
-        if (valid(c)) s_pi[(size_t)tok * LDK + c] = live ? pi[v] * inv : 0.0f;
+        for (int v = 0; v < L::V; ++v) {
+          if constexpr (!MFMA) zkeep[ps][v] = z[v];
+          pn[v] = live ? pi[v] * inv : 0.0f;
+        }
+        store_slots<L>(s_pi + (size_t)tok * LDK, g, K, pn);
+      } else {
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) {
+          zkeep[ps][v] = z[v];
+          const int c = L::cls(g, v);
+          if (c < K) s_pi[(size_t)tok * LDK + c] = live ? pi[v] * inv : 0.0f;
+        }
       }
       cekeep[ps] = 0;
       if constexpr (MODE == DENSE_LOSS) {
@@ -469,11 +479,9 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       }
       if (need_post) {
         if (ps + 1 < NP) gather(ps + 1);
+        load_slots<L>(s_f2 + (size_t)tok * LDK, g, K, 1.0f, f2e);
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          const int c = L::cls(g, v);
-          f2e[v] = (valid(c) ? s_f2[(size_t)tok * LDK + c] : 1.0f) + eps;
-        }
+        for (int v = 0; v < L::V; ++v) f2e[v] += eps;
       }
       if constexpr (MFMA && !GRAD) {
         if (ps == NP - 1 && more) fetch_tile(tile0 + C::TM);
@@ -497,15 +505,22 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
           zm = group_sum<L::G>(zm);
           zt = group_sum<L::G>(zt);
           const float izm = fast_rcp(zm), izt = fast_rcp(zt), zr = zm * izt;
-          float kl = 0;
+          float kl = 0, gf2[L::V];
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
             const float br = bv[v] * fast_rcp(f2e[v]);                     // b_j / f2_j
             kl = fmaf(av[v] * bv[v], fast_log2(br * zr), kl);              // av = 0 on masked slots
-            if constexpr (GRAD) {
-              const float gf2 = w_vb * av[v] * fmaf(-br, izt, izm);
-              if (valid(c)) s_f2[(size_t)tok * LDK + c] = live ? gf2 : 0.0f;
+            if constexpr (GRAD) gf2[v] = live ? w_vb * av[v] * fmaf(-br, izt, izm) : 0.0f;
+          }
+          if constexpr (GRAD) {
+            if constexpr (L::VEC) {
+              store_slots<L>(s_f2 + (size_t)tok * LDK, g, K, gf2);
+            } else {
+#pragma unroll
+              for (int v = 0; v < L::V; ++v) {
+                const int c = L::cls(g, v);
+                if (c < K) s_f2[(size_t)tok * LDK + c] = gf2[v];
+              }
             }
           }
           vb = group_sum<L::G>(kl) * izt * LN2;                            // nats, like ce
@@ -597,21 +612,12 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         }
         if (pos >= p1) continue;     // whole lane groups leave together
         const long n = (long)b * a.npos + pos;
-        if constexpr (!MFMA) {
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
-            pi[v] = valid(c) ? s_pi[(size_t)tok * LDK + c] : 0.0f;
-          }
-        }
+        if constexpr (!MFMA) load_slots<L>(s_pi + (size_t)tok * LDK, g, K, 0.0f, pi);
         if (need_post) {
           float gp[L::V], dot = 0;
+          load_slots<L>(s_gp + (size_t)tok * LDK, g, K, 0.0f, gp);
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const int c = L::cls(g, v);
-            gp[v] = valid(c) ? s_gp[(size_t)tok * LDK + c] : 0.0f;
-            dot = fmaf(pi[v], gp[v], dot);
-          }
+          for (int v = 0; v < L::V; ++v) dot = fmaf(pi[v], gp[v], dot);
           dot = group_sum<L::G>(dot);
 #pragma unroll
           for (int v = 0; v < L::V; ++v)
