@@ -16,7 +16,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o writ
 echo "hbm counters done"
 timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $O -o sq -- python3 $B > $O/sq.log 2>&1
 echo "sq counters done"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o dense -- python3 $K --reps 10 > $O/dense.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o dense -- python3 $K --reps 100 > $O/dense.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O -o mfma -- python3 $K --reps 3 > $O/mfma.log 2>&1
 echo "dense done"
 cd $R
