@@ -2,7 +2,7 @@
 """In-kernel timeline of the fused loss kernel (debug build of the library).
 
     hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -shared -DD3PM_TIMELINE [-DD3PM_TL_ROWS] \
-        csrc/tables.hip csrc/image_structured.hip csrc/protein.hip -o tools/micro/libd3pm_timeline.so
+        csrc/tables.hip csrc/image_structured.hip csrc/protein.hip csrc/logistic.hip -o tools/micro/libd3pm_timeline.so
     D3PM_LIB=tools/micro/libd3pm_timeline.so python tools/timeline.py
 
 Prints, per recorded point, the spread over workgroups of the 100 MHz wall clock
