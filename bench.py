@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--compat", action="store_true",
                     help="time training_losses(...).mean().backward() instead of the two-launch training_step")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="consecutive steps captured in one HIP graph (a graph launch costs ~19 us of host time: with one "
+                         "step per graph the host, not the GPU, bounds the step rate)")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (reverse sampling, K=256 image configuration); for counter passes")
@@ -126,7 +129,7 @@ def main():
     from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
 
     # Default: DiscreteDiffusion.training_step -- timestep draw + q_sample (one launch, device Philox), fused loss
-    # with batch mean and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
+    # per example and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
     # --compat: the reference-shaped calls, training_losses(...).mean().backward(), which add the caller's
     # reduction and its backward (four more short launches on [B] tensors).
     def make_step(compat, graph):
@@ -149,6 +152,19 @@ def main():
 
     step = make_step(args.compat, not args.no_graph)
     other = make_step(not args.compat, not args.no_graph) if not args.no_secondary else None
+    # n consecutive steps per graph replay (default step shape only): K timed steps = K // n replays of the n-step
+    # graph + K % n replays of the one-step graph
+    spg = args.steps_per_graph if not (args.compat or args.no_graph) else 1
+    multi = (d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=4321 + rank, params=[logits], steps=spg).replay
+             if spg > 1 else None)
+
+    def run_steps(k):
+        if multi is not None:
+            for _ in range(k // spg):
+                multi()
+            k %= spg
+        for _ in range(k):
+            step()
 
     # secondary: reverse sampling of 10k BLAT-length sequences, sharded; the 499-step loop of a sub-batch is one graph
     samplers, sub = None, 0
@@ -173,18 +189,15 @@ def main():
     # part that has just left idle); then the W warm-up steps and the K timed ones
     ramp_until = time.perf_counter() + 0.2
     while time.perf_counter() < ramp_until:
-        for _ in range(50):
-            step()
+        run_steps(48)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -196,6 +209,16 @@ def main():
         elapsed = float(el.item())
     tokens = B * L * args.steps * world
 
+    single_ms = None
+    if multi is not None:           # for the record: one step per graph replay (host-launch-bound)
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - s0) * 5.0
     other_ms = None
     if not args.no_secondary:       # the other call shape, for the record (same graph/eager mode, 100 steps)
         for _ in range(10):
@@ -306,10 +329,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic protein D3PM B={B} L={L} K={K} T={T} {args.kind} Q, per GPU: timestep draw + "
-                                   "q_sample (Philox) + fused posterior/hybrid-loss fwd+bwd to dlogits with batch mean, "
+                                   "q_sample (Philox) + fused posterior/hybrid-loss fwd+bwd to per-example losses and dlogits (of the batch mean), "
                                    "denoiser excluded",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective",
-                       "launch": "eager" if args.no_graph else "hip-graph replay",
+                       "launch": "eager" if args.no_graph else f"hip-graph replay, {spg} step(s) per graph",
+                       "one_step_per_graph_ms_per_step": single_ms,
                        "calls": "training_losses(...).mean().backward()" if args.compat else "training_step(...)",
                        "other_call_shape_ms_per_step": other_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -119,7 +119,9 @@ __device__ __forceinline__ int draw_timestep(int b, int T, uint64_t offset, uint
 
 __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t seed, uint64_t offset,
                                                          const uint64_t* __restrict__ offset_dev,
-                                                         int32_t* __restrict__ t_draw, int64_t* __restrict__ out) {
+                                                         int32_t* __restrict__ t_draw, float* __restrict__ clear,
+                                                         int64_t* __restrict__ out) {
+  if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
   __shared__ float cdf[257];     // cdf[j] = sum_{i<j} (off_i + eps)
   __shared__ float dmo[256];     // diag_j - off_j
   const int K = a.tb.K;
@@ -329,22 +331,10 @@ struct LossOut {
   // every reader of the old value (the corruption kernel) finished before this
   // launch began, the next reader starts after it ends
   unsigned long long* rng_counter; unsigned long long rng_step;
+  // batch mean (may be null): every batch element adds loss[b] * inv_B with one device-scope atomic; the caller
+  // zeroes it before the launch (d3pm_q_sample_draw_t does, in the step's first launch)
+  float* mean; float inv_B;
 };
-
-// Optional tail of the loss step, a single small workgroup launched behind the loss
-// kernel(s): the mean of loss[0..B) summed in a fixed order.  (Folding this into
-// the last workgroup of the loss kernel needs device-scope release fences, which
-// on a multi-XCD part write back the whole L2 and cost more than this launch:
-// measured 18.8 us against 10.5 + 2.5 us.)
-__global__ __launch_bounds__(256) void k_batch_mean(const float* __restrict__ loss, int B, float* __restrict__ mean) {
-  __shared__ float red[4];
-  float acc = 0;
-  for (int i = threadIdx.x; i < B; i += 256) acc += loss[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) *mean = (((red[0] + red[1]) + red[2]) + red[3]) / (float)B;
-}
 
 __device__ __forceinline__ void write_losses(const LossOut& o, int b, float svb, float sce, long npos, int loss_type,
                                              float hybrid_coeff) {
@@ -352,7 +342,13 @@ __device__ __forceinline__ void write_losses(const LossOut& o, int b, float svb,
   const float v = svb / (float)npos, c_ = sce / (float)npos;
   if (o.vb) o.vb[b] = v;
   if (o.ce) o.ce[b] = c_;
-  if (o.loss) o.loss[b] = loss_type == D3PM_LOSS_KL ? v : (loss_type == D3PM_LOSS_CE ? c_ : v + hybrid_coeff * c_);
+  const float l = loss_type == D3PM_LOSS_KL ? v : (loss_type == D3PM_LOSS_CE ? c_ : v + hybrid_coeff * c_);
+  if (o.loss) o.loss[b] = l;
+  // One float atomic per batch element, performed at the memory side: no fence, no extra launch.  (A last-workgroup
+  // reduction needs device-scope release fences, which on a multi-XCD part write back the whole L2: 18.8 us against
+  // 10.5; a separate one-workgroup launch costs 3.6 us plus a dependent graph node.)  The order of the B additions
+  // varies from run to run, so the mean is reproducible to float32 rounding of a B-term sum, not bit for bit.
+  if (o.mean) __hip_atomic_fetch_add(o.mean, l * o.inv_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Debug builds (-DD3PM_TIMELINE) record the 100 MHz wall clock at a few points of
@@ -823,7 +819,7 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
   if (noise_kind == D3PM_NOISE_PHILOX) {
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, 1);    // one thread per token
     hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev,
-                       (int32_t*)nullptr, x_t);
+                       (int32_t*)nullptr, (float*)nullptr, x_t);
     D3PM_LAUNCH_CHECK("k_q_sample_icdf");
     return D3PM_OK;
   }
@@ -846,22 +842,24 @@ extern "C" int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_
 }
 
 __global__ void k_draw_t(int B, int T, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
-                         int32_t* __restrict__ t_draw) {
+                         int32_t* __restrict__ t_draw, float* __restrict__ clear) {
+  if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
   if (offset_dev) offset += *offset_dev;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) t_draw[b] = draw_timestep(b, T, offset, seed);
 }
 
 extern "C" int d3pm_q_sample_draw_t(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
-                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* t_out,
-                                    int64_t* x_t, void* stream) {
+                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* clear,
+                                    int32_t* t_out, int64_t* x_t, void* stream) {
   if (int rc = check_common(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(bytes_ok(tok_bytes), "token width must be 4 or 8 bytes");
   if (B == 0) return D3PM_OK;
   D3PM_CHECK_ARG(t_out, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (npos == 0 || !tb->structured) {
-    hipLaunchKernelGGL(k_draw_t, dim3((B + 255) / 256), dim3(256), 0, s, B, tb->T, seed, offset, offset_dev, t_out);
+    hipLaunchKernelGGL(k_draw_t, dim3((B + 255) / 256), dim3(256), 0, s, B, tb->T, seed, offset, offset_dev, t_out,
+                       clear);
     D3PM_LAUNCH_CHECK("k_draw_t");
     if (npos == 0) return D3PM_OK;
     D3PM_CHECK_ARG(x0 && x_t, "null pointer");
@@ -870,7 +868,8 @@ extern "C" int d3pm_q_sample_draw_t(const d3pm_tables_f32* tb, const void* x0, i
   }
   D3PM_CHECK_ARG(x0 && x_t, "null pointer");
   ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, nullptr, 4, B, npos, 1);    // one thread per token
-  hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev, t_out, x_t);
+  hipLaunchKernelGGL(k_q_sample_icdf, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, seed, offset, offset_dev, t_out, clear,
+                     x_t);
   D3PM_LAUNCH_CHECK("k_q_sample_icdf");
   return D3PM_OK;
 }
@@ -933,8 +932,8 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
   D3PM_CHECK_ARG(npos * ld < 0x3fffffffL, "one batch element spans %ld logits: more than 2^30", npos * ld);
   D3PM_CHECK_ARG(logits && x0 && x_t && t, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  D3PM_CHECK_ARG(!loss_mean || loss, "the batch mean needs the per-sample loss output");
-  LossOut o{vb, ce, loss, nullptr, (unsigned long long*)rng_counter, (unsigned long long)rng_step};
+  LossOut o{vb, ce, loss, nullptr, (unsigned long long*)rng_counter, (unsigned long long)rng_step, loss_mean,
+            1.0f / (float)B};
   int rc;
   if (!tb->structured) {
     rc = dense_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type, hybrid_coeff,
@@ -943,12 +942,7 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
     rc = structured_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
                                 hybrid_coeff, grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
   }
-  if (rc) return rc;
-  if (loss_mean) {
-    hipLaunchKernelGGL(k_batch_mean, dim3(1), dim3(256), 0, s, loss, B, loss_mean);
-    D3PM_LAUNCH_CHECK("k_batch_mean");
-  }
-  return D3PM_OK;
+  return rc;
 }
 
 static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,

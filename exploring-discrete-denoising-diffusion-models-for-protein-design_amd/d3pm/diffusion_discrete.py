@@ -57,6 +57,18 @@ def _philox_ticket(device) -> tuple:
     return seed & 0xFFFFFFFFFFFFFFFF, off
 
 
+class StepResult(dict):
+    """What ``training_step`` returns.  ``['loss']``, the batch mean, is reduced
+    from ``['losses']`` whenever it is read (one small launch on the current
+    stream, after a graph replay too) unless the step was asked to produce it on
+    the device."""
+
+    def __missing__(self, key):
+        if key == "loss":
+            return self["losses"].mean()
+        raise KeyError(key)
+
+
 class _LogisticLogits(torch.autograd.Function):
     """Bin logits of the discretised logistic and their gradient to (loc,
     log_scale): one kernel each way."""
@@ -437,7 +449,7 @@ class DiscreteDiffusion:
         assert losses.shape == t.shape
         return losses
 
-    def training_step(self, model_fn, *, x_start, rng=None, backward=True):
+    def training_step(self, model_fn, *, x_start, rng=None, backward=True, device_mean=False):
         """One training step of the path in two launches around the denoiser.
 
         The reference's step is ``training_losses(...)`` (:545-582) followed by the
@@ -450,9 +462,12 @@ class DiscreteDiffusion:
         device tensor (advanced by the loss kernel itself, for HIP-graph replay),
         or torch's CUDA generator when ``rng`` is None.
 
-        Returns a dict: ``loss`` (scalar float32 tensor, mean over the batch),
-        ``losses`` [B], ``t`` [B] int32, ``x_t``; gradients are accumulated into
-        whatever the logits depend on when ``backward`` is true."""
+        Returns a dict: ``losses`` [B], ``t`` [B] int32, ``x_t``, and ``loss`` (scalar
+        float32 tensor, mean over the batch: reduced from ``losses`` when read, or
+        with ``device_mean`` accumulated by the loss kernel itself with one atomic
+        per batch element, which lengthens that kernel by ~2.8 us at B = 256);
+        gradients -- of the batch mean either way -- are accumulated into whatever
+        the logits depend on when ``backward`` is true."""
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         if self.model_prediction != "x_start":
@@ -471,9 +486,10 @@ class DiscreteDiffusion:
             seed, off = _philox_ticket(dev)
         t = torch.empty(B, dtype=torch.int32, device=dev)
         x_t = torch.empty(x0.shape, dtype=torch.int64, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev) if device_mean else None   # zeroed by the first launch
         with torch.cuda.device(dev):
-            check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(t),
-                                           ptr(x_t), stream_ptr()))
+            check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(mean),
+                                           ptr(t), ptr(x_t), stream_ptr()))
         pred = self._denoiser_logits(model_fn, x_t, t)
         assert pred.shape == x0.shape + (tb.K,), pred.shape
         lg = pred.detach().contiguous()
@@ -481,7 +497,6 @@ class DiscreteDiffusion:
             lg = lg.float()
         want_grad = backward and pred.requires_grad
         losses = torch.empty(B, dtype=torch.float32, device=dev)
-        mean = torch.empty((), dtype=torch.float32, device=dev)
         dl = torch.empty_like(lg) if want_grad else None
         ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
@@ -495,7 +510,10 @@ class DiscreteDiffusion:
             holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
             del dl
             torch.autograd.backward(_Handoff.apply(pred, holder), self._unit(dev))
-        return {"loss": mean, "losses": losses, "t": t, "x_t": x_t}
+        out = StepResult(losses=losses, t=t, x_t=x_t)
+        if device_mean:
+            out["loss"] = mean
+        return out
 
     def _unit(self, dev):
         one = getattr(self, "_one", None)

@@ -65,12 +65,25 @@ class GraphedTrainingStep:
     backward through the denoiser -- captured once and replayed.  The Philox
     counter lives on the device and is advanced by the loss kernel, so the graph
     holds no bookkeeping launches at all.  Arguments as for
-    ``GraphedTrainingLosses``; ``replay()`` returns the static result dict."""
+    ``GraphedTrainingLosses``; ``replay()`` returns the static result dict.
 
-    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0, warmup: int = 3, params=()):
-        self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
-        self.seed = int(seed)
-        dev = x_start.device
+    ``steps`` > 1 captures that many consecutive steps in one graph (a replay then
+    costs one host-side graph launch, ~19 us, for all of them: with one step of
+    ~17 us of GPU work per graph the host is the bound).  ``x_start`` is then
+    either one batch buffer read by every step or a sequence of ``steps`` buffers
+    (a ring of pre-staged batches); ``params``' gradients are cleared before each
+    captured step, so after a replay they hold the last step's gradient --
+    capture the optimiser inside ``model_fn``'s backward hooks or use ``steps=1``
+    when every step's gradient is consumed on the host side.  ``outs`` lists the
+    result dict of every captured step, ``out`` is the last."""
+
+    def __init__(self, diffusion, model_fn, x_start, seed: int = 0, warmup: int = 3, params=(), steps: int = 1):
+        self.diffusion, self.model_fn = diffusion, model_fn
+        self.batches = list(x_start) if isinstance(x_start, (list, tuple)) else [x_start] * steps
+        assert len(self.batches) == steps >= 1
+        self.x_start = self.batches[0]
+        self.seed, self.steps = int(seed), steps
+        dev = self.x_start.device
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         diffusion.tables()
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -78,16 +91,19 @@ class GraphedTrainingStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._body()
+                self._body(self.x_start)
         torch.cuda.current_stream(dev).wait_stream(side)
-        for p in params:
-            p.grad = None
         self.graph = torch.cuda.CUDAGraph()
+        self.outs = []
         with torch.cuda.graph(self.graph):
-            self.out = self._body()
+            for x in self.batches:
+                for p in params:
+                    p.grad = None
+                self.outs.append(self._body(x))
+        self.out = self.outs[-1]
 
-    def _body(self):
-        return self.diffusion.training_step(self.model_fn, x_start=self.x_start, rng=(self.seed, self.counter))
+    def _body(self, x):
+        return self.diffusion.training_step(self.model_fn, x_start=x, rng=(self.seed, self.counter))
 
     def replay(self):
         self.graph.replay()

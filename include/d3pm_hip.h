@@ -136,10 +136,12 @@ int d3pm_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, cons
 /* The first two lines of training_losses (:549-556) with on-device noise: t_b
  * uniform on [0, T) for every batch element (t_out int32 [B], the reference
  * draws torch.randint) and x_t = q_sample(x0, t), one launch for column-
- * structured tables.  Philox stream as for d3pm_q_sample. */
+ * structured tables.  Philox stream as for d3pm_q_sample.  clear (may be
+ * NULL): one float32 the kernel sets to 0 -- the loss_mean accumulator of the
+ * d3pm_hybrid_loss launch that follows in the same step. */
 int d3pm_q_sample_draw_t(const d3pm_tables_f32* tb, const void* x0, int tok_bytes, int B, long npos,
-                         uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* t_out,
-                         int64_t* x_t, void* stream);
+                         uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* clear,
+                         int32_t* t_out, int64_t* x_t, void* stream);
 
 /* q_posterior_logits (:312-336).  x_start_is_logits == 0: x_start is a token
  * array; != 0: float32 logits [B,npos,ld].  out float32 [B,npos,K].  With
@@ -160,9 +162,13 @@ size_t d3pm_hybrid_loss_workspace(int B, long npos, int K);
  *   grad_out float32 [B] upstream gradient per sample, or NULL for all ones
  *   vb, ce, loss  float32 [B] (any may be NULL)
  *   dlogits float32 [B,npos,ld] or NULL (forward only); columns >= K get 0
- *   loss_mean (may be NULL): float32 scalar, mean of loss[0..B) summed in a
- *     fixed order -- the `.mean()` of the training loop (:582 returns [B]; the
- *     notebook reduces it); one single-workgroup launch behind the loss kernel
+ *   loss_mean (may be NULL): float32 scalar that must hold 0 on entry (the
+ *     `clear` argument of d3pm_q_sample_draw_t zeroes it in the step's first
+ *     launch); every batch element adds loss[b]/B to it with one device-scope
+ *     atomic -- the `.mean()` of the training loop (:582 returns [B]; the
+ *     notebook reduces it) with no launch of its own.  The order of the B
+ *     additions varies: equal to the mean up to float32 rounding, not bit for
+ *     bit from run to run (loss[] itself is summed in a fixed order)
  *   rng_counter (may be NULL): *rng_counter += rng_step, done by the loss kernel;
  *     the device-side Philox counter of d3pm_q_sample(_draw_t), so that a
  *     captured HIP graph needs no separate increment

@@ -521,3 +521,35 @@ def test_training_step_timestep_distribution_and_graph(pkg):
     assert counts.min() > 0 and chi2 < T + 6 * np.sqrt(2 * T), chi2    # uniform on [0, T): chi-square within 6 sigma
     ref = d._fused(logits.detach(), x0, out["x_t"], out["t"], "hybrid")
     assert torch.equal(out["losses"], ref)
+    np.testing.assert_allclose(float(out["loss"]), float(ref.double().mean()), rtol=1e-5)     # reduced when read
+    # on the device: accumulated with one atomic per batch element, equal to the mean up to summation order
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    dm = d.training_step(lambda x, tt: logits, x_start=x0, rng=(9, counter), device_mean=True)
+    assert "loss" in dm and dm["loss"].shape == ()
+    np.testing.assert_allclose(float(dm["loss"]), float(dm["losses"].double().mean()), rtol=1e-5)
+
+
+def test_training_step_several_steps_per_graph(pkg):
+    """Three consecutive steps captured in one graph over a ring of three batches
+    equal three eager steps on the same Philox counter values."""
+    K, T, B, L = 32, 500, 64, 48
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    ring = [torch.randint(0, K, (B, L, 1, 1), device=DEV) for _ in range(3)]
+    logits = torch.randn(B, L, 1, 1, K, device=DEV, requires_grad=True)
+    fn = lambda x, tt: logits
+    g = pkg.graphs.GraphedTrainingStep(d, fn, ring, seed=5, params=[logits], steps=3, warmup=1)
+    start = int(g.counter.item())                   # the warm-up step advanced it
+    g.replay()
+    assert int(g.counter.item()) == start + 12      # three steps of four Philox offsets each
+    grad_graph = logits.grad.clone()
+    counter = torch.full((1,), start, dtype=torch.int64, device=DEV)
+    for i in range(3):
+        logits.grad = None
+        e = d.training_step(fn, x_start=ring[i], rng=(5, counter))
+        for k in ("t", "x_t", "losses"):
+            assert torch.equal(g.outs[i][k], e[k]), (i, k)
+        np.testing.assert_allclose(float(g.outs[i]["loss"]), float(e["loss"]), rtol=1e-5)
+    assert torch.equal(grad_graph, logits.grad)      # the last step's gradient
+    assert not torch.equal(g.outs[0]["t"], g.outs[1]["t"])

@@ -62,6 +62,12 @@ def main():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(x_t), 8, ptr(t), 4, B, L, LOSS["hybrid"],
                                    0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb, s))
 
+    mean_acc = torch.zeros((), device=dev)
+
+    def f_loss_mean():      # batch mean accumulated by atomics (accumulator not re-zeroed here: timing only)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(x_t), 8, ptr(t), 4, B, L, LOSS["hybrid"],
+                                   0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), ptr(mean_acc), None, 0, ptr(ws), wsb, s))
+
     def f_loss_fwd():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(x_t), 8, ptr(t), 4, B, L, LOSS["hybrid"],
                                    0.001, 1.0 / B, None, None, None, ptr(loss), None, None, None, 0, ptr(ws), wsb, s))
@@ -94,7 +100,8 @@ def main():
     def f_logistic_bwd():
         check(lib.d3pm_logistic_logits_backward(ptr(loc), ptr(lsc), ptr(cen), ptr(logits), N, K, 1e-6, ptr(dloc), ptr(dlsc), s))
 
-    for name, fn, bytes_per_tok in (("hybrid_loss fwd+bwd", f_loss, 8 * K + 16), ("hybrid_loss fwd", f_loss_fwd, 4 * K + 16),
+    for name, fn, bytes_per_tok in (("hybrid_loss fwd+bwd", f_loss, 8 * K + 16), ("hybrid_loss fwd+bwd + atomic mean", f_loss_mean, 8 * K + 16),
+                                    ("hybrid_loss fwd", f_loss_fwd, 4 * K + 16),
                                     ("q_sample philox", f_qs, 16), ("p_sample philox", f_ps, 4 * K + 16),
                                     ("logistic head fwd", f_logistic, 4 * K + 8), ("logistic head bwd", f_logistic_bwd, 4 * K + 16),
                                     ("torch copy_ (reference stream)", f_copy, 8 * K),
