@@ -1,5 +1,15 @@
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Step time of the graph-replayed training step against the number of consecutive
+steps captured per graph: GPU time per step and host time spent issuing the replays.
+One step per graph is bound by the host-side graph launch (~19 us), from about four
+steps per graph on the GPU is the bound."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import d3pm_amd
 B, L, K, T = 256, 512, 32, 500
 dev = torch.device('cuda', 0)
