@@ -345,7 +345,10 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
 // uses the hardware exp2, and the uniforms come from a per-wave pool: one Philox
 // call per lane yields 256 words per wave, parked in LDS and handed out one word
 // per token (a 32-bit uniform) over the next 256 / tokens-per-pass passes.
-template <class L>
+// PAIR: rows are read as 8-byte pairs (even row stride, 8-byte aligned base): lane g owns the class pairs g, g + G,
+// ... -- half the load instructions and address arithmetic of the one-class-per-load strided layout, and no
+// per-slot bounds branches (a pair past the row end re-reads the row's last pair and is masked afterwards).
+template <class L, bool PAIR>
 __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a, const float* __restrict__ pred, long ld,
                                                                      uint64_t seed, uint64_t offset,
                                                                      const uint64_t* __restrict__ offset_dev,
@@ -358,6 +361,8 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   __shared__ uint32_t pool[WAVES][256];
   __shared__ float s_ad[256], s_ao[256];                    // column x_t of Q_t: diagonal / off-diagonal entry by x_t
   const int K = a.tb.K;
+  static_assert(!PAIR || L::V % 2 == 0, "pairs need an even number of slots per lane");
+  auto cls = [](int gg, int vv) { return PAIR ? 2 * (gg + L::G * (vv >> 1)) + (vv & 1) : L::cls(gg, vv); };
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tok_in_wave = lane / L::G;
@@ -369,7 +374,17 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   int xq[PF];
   auto fetch = [&](int u, long pos) {
     const long n = (long)b * a.npos + (pos < p1 ? pos : pbeg < p1 ? pbeg : 0);
-    load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, zq[u]);
+    if constexpr (PAIR) {
+      const float* row = pred + n * ld;
+      const int last_pair = (int)(ld >> 1) - 1;
+#pragma unroll
+      for (int j = 0; j < L::V / 2; ++j) {
+        const float2 q = *reinterpret_cast<const float2*>(row + 2 * min(g + L::G * j, last_pair));
+        zq[u][2 * j] = q.x; zq[u][2 * j + 1] = q.y;
+      }
+    } else {
+      load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, zq[u]);
+    }
     xq[u] = (int)a.xt[n];
   };
   if (pbeg < p1 || chunk * a.chunk_pos < p1) {
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   float md[L::V], mo[L::V];
 #pragma unroll
   for (int v = 0; v < L::V; ++v) {
-    const int c = L::cls(g, v);
+    const int c = cls(g, v);
     md[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
     mo[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
   }
@@ -409,12 +424,12 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
       const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
       float m = -INFINITY;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) m = fmaxf(m, (L::cls(g, v) < K) ? z[v] : -INFINITY);
+      for (int v = 0; v < L::V; ++v) m = fmaxf(m, (cls(g, v) < K) ? z[v] : -INFINITY);
       m = group_max<L::G>(m);
       float p[L::V], s2 = 0;
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        p[v] = (L::cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
+        p[v] = (cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
         s2 = fmaf(p[v], p[v], s2);
       }
       s2 = group_sum<L::G>(s2);       // the softmax normaliser cancels in the draw: p stays unnormalised
@@ -423,13 +438,13 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
       float r[L::V];
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        const int c = L::cls(g, v);
+        const int c = cls(g, v);
         const float pp = p[v] * p[v];
         r[v] = (c < K) ? ((c == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp) : 0.0f;
         if (c == K - 1) r[v] = no_last ? 0.0f : r[v] * inv_last;
       }
       const float u01v = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
-      const int pick = group_pick<L::G, L::V>(r, g, u01v, xt, [](int gg, int vv) { return L::cls(gg, vv); });
+      const int pick = group_pick<L::G, L::V>(r, g, u01v, xt, cls);
       if (g == 0 && pos < p1) out[(long)b * a.npos + pos] = pick;
     }
   }
@@ -529,8 +544,16 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
       ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
       const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, rev_blocks);   // long trips: rows are prefetched 3 passes ahead
       a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
-      hipLaunchKernelGGL(k_lvb_reverse_device_noise<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred,
-                         ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      if constexpr (L::V % 2 == 0) {
+        if (ld % 2 == 0 && ((uintptr_t)pred & 7) == 0) {
+          hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, true>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream,
+                             a, pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+          D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
+          return D3PM_OK;
+        }
+      }
+      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a,
+                         pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
       D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
       return D3PM_OK;
     };
@@ -544,8 +567,8 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
     if (!expo) {
       const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, 1024);
       a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
-      hipLaunchKernelGGL(k_lvb_reverse_device_noise<L>, dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a, pred,
-                         ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a,
+                         pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
       D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
       return D3PM_OK;
     }

@@ -151,20 +151,22 @@ def test_non_uniform_tables_fail_loudly(pkg):
         protein_tables(Q, Q)
 
 
-def test_reverse_step_device_noise_distribution(pkg, tables500):
+@pytest.mark.parametrize("n_tok", [24, 22, 23])
+def test_reverse_step_device_noise_distribution(pkg, tables500, n_tok):
     """Device-noise mode draws with one uniform per token (inverse CDF): the
-    empirical class frequencies must match the oracle's marginal."""
+    empirical class frequencies must match the oracle's marginal.  Even row
+    strides are read as 8-byte pairs, odd ones class by class."""
     from d3pm_amd.protein_generation.generate import reverse_step
     from d3pm_amd.tables import protein_tables
     tok, Qb, Qt = tables500
     tb = protein_tables(Qt, Qb)
     gen = torch.Generator().manual_seed(5)
     for t in (400, 3):
-        logits1 = torch.randn(1, 24, generator=gen) * 1.5
+        logits1 = torch.randn(1, n_tok, generator=gen) * 1.5
         # (two identical positions: the oracle's squeeze() needs more than one)
-        P = pr.reverse_marginal(logits1.expand(2, 24), torch.tensor([7, 7]), Qt.cpu()[t], Qb.cpu()[t - 1])[0].numpy()
+        P = pr.reverse_marginal(logits1.expand(2, n_tok), torch.tensor([7, 7]), Qt.cpu()[t], Qb.cpu()[t - 1])[0].numpy()
         Bn, Ln = 64, 4096
-        logits = logits1.expand(Bn, Ln, 24).contiguous().to(DEV)
+        logits = logits1.expand(Bn, Ln, n_tok).contiguous().to(DEV)
         x = torch.full((Bn, Ln), 7, device=DEV)
         torch.manual_seed(11)
         out = reverse_step(tb, logits, x, torch.full((Bn,), t, device=DEV))
