@@ -372,20 +372,24 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   // rows and tokens of the first passes are requested before the timestep -> digest chain
   float zq[PF][L::V];
   int xq[PF];
+  // this batch element's rows and tokens through workgroup-uniform bases and 32-bit byte offsets (the host checks
+  // that one batch element spans less than 2^31 bytes): no 64-bit address arithmetic per lane
+  const char* pred_b = reinterpret_cast<const char*>(pred + (long)b * a.npos * ld);
+  const char* xt_b = reinterpret_cast<const char*>(a.xt + (long)b * a.npos);
+  const unsigned ld_u = (unsigned)ld, last_pair = (unsigned)(ld >> 1) - 1u;
   auto fetch = [&](int u, long pos) {
-    const long n = (long)b * a.npos + (pos < p1 ? pos : pbeg < p1 ? pbeg : 0);
+    const unsigned pc = (unsigned)(pos < p1 ? pos : pbeg < p1 ? pbeg : 0);
     if constexpr (PAIR) {
-      const float* row = pred + n * ld;
-      const int last_pair = (int)(ld >> 1) - 1;
 #pragma unroll
       for (int j = 0; j < L::V / 2; ++j) {
-        const float2 q = *reinterpret_cast<const float2*>(row + 2 * min(g + L::G * j, last_pair));
+        const unsigned off = (pc * ld_u + 2u * min((unsigned)(g + L::G * j), last_pair)) * 4u;
+        const float2 q = *reinterpret_cast<const float2*>(pred_b + off);
         zq[u][2 * j] = q.x; zq[u][2 * j + 1] = q.y;
       }
     } else {
-      load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, zq[u]);
+      load_slots<L>(reinterpret_cast<const float*>(pred_b) + (size_t)pc * ld_u, g, (int)ld, -INFINITY, zq[u]);
     }
-    xq[u] = (int)a.xt[n];
+    xq[u] = (int)*reinterpret_cast<const int64_t*>(xt_b + pc * 8u);
   };
   if (pbeg < p1 || chunk * a.chunk_pos < p1) {
 #pragma unroll
@@ -535,6 +539,7 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   D3PM_CHECK_ARG(last_class_div > 0.0 && exclude_last_prefix >= 0, "last-class divisor must be positive, prefix >= 0");
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
+  D3PM_CHECK_ARG(npos * ld < 0x1fffffffL, "one batch element spans %ld predictions: more than 2^29", npos * ld);
   if (!expo && ld <= 32) {
     // few lanes per token: the draw is cheap per class, the cross-lane steps are what costs
     static const int rev_blocks = getenv("D3PM_REV_BLOCKS") ? atoi(getenv("D3PM_REV_BLOCKS")) : 1024;
