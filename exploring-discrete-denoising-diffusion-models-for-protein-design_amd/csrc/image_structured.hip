@@ -494,7 +494,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
         if (nxt1 < p1) issue_special((u + 1) % PIPE, nxt1);
         if (nxt < p1) issue_load(u, nxt);
       }
-      // ---- round 1, 2: softmax of z
+      // ---- reductions 1 and 2: softmax of z
       float m = z[0];
 #pragma unroll
       for (int v = 1; v < L::V; ++v) m = fmaxf(m, z[v]);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
         const float a_d = s_ad[xt], a_o = s_ao[xt], da = a_d - a_o;
         const float bdo_x0 = s_bdo[x0], boe_x0 = s_boe[x0], bdo_xt = s_bdo[xt], boe_xt = s_boe[xt];
         const float same = (x0 == xt) ? 1.0f : 0.0f;
-        // ---- round 3: generic-class sums
+        // ---- reduction 3: generic-class sums
         float pr[L::V], Sf = 0, Rp = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
         // is close to one wherever q_j is large, so nothing cancels
         const float zr = Zm * izt;
         const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
-        // ---- round 4: kl sum, <pi, g pi>
+        // ---- reduction 4: kl sum, <pi, g pi>
         float h[L::V], S1 = 0, D = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {

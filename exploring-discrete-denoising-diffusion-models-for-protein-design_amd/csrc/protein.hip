@@ -348,14 +348,16 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
 // PAIR: rows are read as 8-byte pairs (even row stride, 8-byte aligned base): lane g owns the class pairs g, g + G,
 // ... -- half the load instructions and address arithmetic of the one-class-per-load strided layout, and no
 // per-slot bounds branches (a pair past the row end re-reads the row's last pair and is masked afterwards).
-template <class L, bool PAIR>
-__global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a, const float* __restrict__ pred, long ld,
+// BLK: threads per workgroup (128, 192 or 256), chosen by the host so that the last, partly filled pass over a
+// chunk wastes the fewest lanes (263 positions: five passes of 64 tokens idle 18 % of the slots, six of 48 idle 9 %).
+template <class L, bool PAIR, int BLK>
+__global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, const float* __restrict__ pred, long ld,
                                                                      uint64_t seed, uint64_t offset,
                                                                      const uint64_t* __restrict__ offset_dev,
                                                                      float last_class_div, long exclude_last_prefix,
                                                                      int64_t* __restrict__ out) {
   if (offset_dev) offset += *offset_dev;
-  constexpr int WAVES = PBLOCK / 64, TPW = 64 / L::G;      // tokens per wave and pass
+  constexpr int WAVES = BLK / 64, TPW = 64 / L::G;      // tokens per wave and pass
   constexpr int REFILL = 256 / TPW;                         // passes served by one pool
   constexpr int PF = 3;                                     // passes whose rows are in flight
   __shared__ uint32_t pool[WAVES][256];
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tok_in_wave = lane / L::G;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   const long pbeg = chunk * a.chunk_pos + slot;
-  constexpr long STEP = PBLOCK / L::G;
+  constexpr long STEP = BLK / L::G;
   // rows and tokens of the first passes are requested before the timestep -> digest chain
   float zq[PF][L::V];
   int xq[PF];
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
     md[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
     mo[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
   }
-  for (int c = threadIdx.x; c < K; c += PBLOCK) {
+  for (int c = threadIdx.x; c < K; c += BLK) {
     s_ad[c] = (float)dgd(a.tb.qone_digest, t, 0, K)[c];
     s_ao[c] = (float)dgd(a.tb.qone_digest, t, 1, K)[c];
   }
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse_device_noise(ProtArgs a,
     for (int u = 0; u < PF; ++u, ++it) {
       if (pos0 + u * STEP >= p1) break;                      // uniform over the workgroup
       if (it % REFILL == 0) {        // wave-private pool: LDS operations of a wave are in order
-        const U4 r = philox4x32_10(((uint64_t)blockIdx.x << 32) + (uint64_t)(it / REFILL) * PBLOCK + threadIdx.x, offset,
+        const U4 r = philox4x32_10(((uint64_t)blockIdx.x << 32) + (uint64_t)(it / REFILL) * BLK + threadIdx.x, offset,
                                    seed);
         pool[wave][lane] = r.x; pool[wave][64 + lane] = r.y; pool[wave][128 + lane] = r.z; pool[wave][192 + lane] = r.w;
       }
@@ -544,23 +546,45 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
     // few lanes per token: the draw is cheap per class, the cross-lane steps are what costs
     static const int rev_blocks = getenv("D3PM_REV_BLOCKS") ? atoi(getenv("D3PM_REV_BLOCKS")) : 1024;
     static const int rev_lanes = getenv("D3PM_REV_LANES") ? atoi(getenv("D3PM_REV_LANES")) : 4;
-    auto launch = [&](auto lay) {
+    auto launch_blk = [&](auto lay, auto blk) {
       using L = decltype(lay);
+      constexpr int BLK = decltype(blk)::value;
       ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, L::G);
-      const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, rev_blocks);   // long trips: rows are prefetched 3 passes ahead
+      const TokenGrid tg = token_grid(B, npos, BLK / L::G, rev_blocks);   // long trips: rows are prefetched 3 passes ahead
       a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
       if constexpr (L::V % 2 == 0) {
         if (ld % 2 == 0 && ((uintptr_t)pred & 7) == 0) {
-          hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, true>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream,
+          hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, true, BLK>), dim3(B * a.chunks), dim3(BLK), 0, (hipStream_t)stream,
                              a, pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
           D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
           return D3PM_OK;
         }
       }
-      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a,
+      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false, BLK>), dim3(B * a.chunks), dim3(BLK), 0, (hipStream_t)stream, a,
                          pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
       D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
       return D3PM_OK;
+    };
+    auto launch = [&](auto lay) {
+      using L = decltype(lay);
+      // workgroup size with the fewest idle token slots over a chunk (ties: the larger workgroup)
+      static const int force = getenv("D3PM_REV_BLOCK") ? atoi(getenv("D3PM_REV_BLOCK")) : 0;
+      int best = 256;
+      long best_slots = -1;
+      for (int blk : {256, 192, 128}) {
+        const TokenGrid tg = token_grid(B, npos, blk / L::G, rev_blocks);
+        const long tpp = blk / L::G;
+        long slots = 0;
+        for (long c0 = 0; c0 < npos; c0 += tg.chunk_pos) {
+          const long n = (npos - c0 < tg.chunk_pos) ? npos - c0 : tg.chunk_pos;
+          slots += (n + tpp - 1) / tpp * tpp;
+        }
+        if (best_slots < 0 || slots < best_slots) { best_slots = slots; best = blk; }
+      }
+      if (force) best = force;
+      if (best == 192) return launch_blk(lay, std::integral_constant<int, 192>{});
+      if (best == 128) return launch_blk(lay, std::integral_constant<int, 128>{});
+      return launch_blk(lay, std::integral_constant<int, 256>{});
     };
     if (rev_lanes == 2) return ld <= 24 ? launch(Layout<2, 12, false>{}) : launch(Layout<2, 16, false>{});
     if (rev_lanes == 4) return ld <= 24 ? launch(Layout<4, 6, false>{}) : launch(Layout<4, 8, false>{});
@@ -572,8 +596,9 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
     if (!expo) {
       const TokenGrid tg = token_grid(B, npos, PBLOCK / L::G, 1024);
       a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
-      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false>), dim3(B * a.chunks), dim3(PBLOCK), 0, (hipStream_t)stream, a,
-                         pred, ld, seed, offset, offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      hipLaunchKernelGGL((k_lvb_reverse_device_noise<L, false, PBLOCK>), dim3(B * a.chunks), dim3(PBLOCK), 0,
+                         (hipStream_t)stream, a, pred, ld, seed, offset, offset_dev, (float)last_class_div,
+                         exclude_last_prefix, out);
       D3PM_LAUNCH_CHECK("k_lvb_reverse_device_noise");
       return D3PM_OK;
     }
