@@ -398,19 +398,25 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
     for (int u = 0; u < PF; ++u) fetch(u, pbeg + u * STEP);
   }
   const int t = (int)a.t[b];
+  // Per-slot constants of the timestep.  Slots past K get zero weights and their logits are replaced by -inf on
+  // arrival, so the loop carries no bounds checks; the divisor of the last class is folded into its two weights
+  // (the draw is linear in them).
+  const float inv_last = 1.0f / last_class_div;
   float md[L::V], mo[L::V];
+  bool valid[L::V];
 #pragma unroll
   for (int v = 0; v < L::V; ++v) {
     const int c = cls(g, v);
-    md[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
-    mo[v] = c < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
+    valid[v] = c < K;
+    const float w = (c == K - 1) ? inv_last : 1.0f;
+    md[v] = valid[v] ? w * (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[c] : 0.0f;
+    mo[v] = valid[v] ? w * (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[c] : 0.0f;
   }
   for (int c = threadIdx.x; c < K; c += BLK) {
     s_ad[c] = (float)dgd(a.tb.qone_digest, t, 0, K)[c];
     s_ao[c] = (float)dgd(a.tb.qone_digest, t, 1, K)[c];
   }
   __syncthreads();
-  const float inv_last = 1.0f / last_class_div;
   int it = 0;
   for (long pos0 = chunk * a.chunk_pos; pos0 < p1; pos0 += PF * STEP) {
 #pragma unroll
@@ -424,30 +430,32 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
       const long pos = pos0 + u * STEP + slot;
       float z[L::V];
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) z[v] = zq[u][v];
+      for (int v = 0; v < L::V; ++v) z[v] = valid[v] ? zq[u][v] : -INFINITY;
       const int xt = xq[u];
       if (pos + PF * STEP - slot < p1) fetch(u, pos + PF * STEP);   // refill this stage (uniform condition)
       const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
       float m = -INFINITY;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) m = fmaxf(m, (cls(g, v) < K) ? z[v] : -INFINITY);
+      for (int v = 0; v < L::V; ++v) m = fmaxf(m, z[v]);
       m = group_max<L::G>(m);
       float p[L::V], s2 = 0;
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        p[v] = (cls(g, v) < K) ? __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f) : 0.0f;
+        p[v] = __builtin_amdgcn_exp2f((z[v] - m) * 1.44269504088896340736f);      // 0 on slots past K
         s2 = fmaf(p[v], p[v], s2);
       }
       s2 = group_sum<L::G>(s2);       // the softmax normaliser cancels in the draw: p stays unnormalised
       const float a_diag = s_ad[xt], a_off = s_ao[xt];
-      const bool no_last = pos < exclude_last_prefix;
       float r[L::V];
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
-        const int c = cls(g, v);
         const float pp = p[v] * p[v];
-        r[v] = (c < K) ? ((c == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp) : 0.0f;
-        if (c == K - 1) r[v] = no_last ? 0.0f : r[v] * inv_last;
+        r[v] = ((cls(g, v) == xt) ? a_diag : a_off) * fmaf(mo[v], s2 - pp, md[v] * pp);
+      }
+      if (exclude_last_prefix > 0) {      // MSA sampling only: the last class cannot be drawn in the query row
+#pragma unroll
+        for (int v = 0; v < L::V; ++v)
+          if (cls(g, v) == K - 1 && pos < exclude_last_prefix) r[v] = 0.0f;
       }
       const float u01v = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
       const int pick = group_pick<L::G, L::V>(r, g, u01v, xt, cls);

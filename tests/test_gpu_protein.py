@@ -177,6 +177,15 @@ def test_reverse_step_device_noise_distribution(pkg, tables500, n_tok):
         freq = torch.bincount(out.flatten().cpu(), minlength=22).numpy() / n
         tol = 5 * np.sqrt(P * (1 - P) / n) + 1e-5
         assert (np.abs(freq - P) < tol).all(), (freq, P)
+        # the MSA sampler's two knobs: last class down-weighted everywhere, excluded in the first half of the positions
+        out = reverse_step(tb, logits, x, torch.full((Bn,), t, device=DEV), last_class_div=1.7, exclude_last_prefix=Ln // 2)
+        for part, w_last in ((out[:, :Ln // 2], 0.0), (out[:, Ln // 2:], 1.0 / 1.7)):
+            Pm = P.copy()
+            Pm[21] *= w_last
+            Pm /= Pm.sum()
+            n = part.numel()
+            freq = torch.bincount(part.flatten().cpu(), minlength=22).numpy() / n
+            assert (np.abs(freq - Pm) < 5 * np.sqrt(Pm * (1 - Pm) / n) + 1e-5).all(), (w_last, freq, Pm)
 
 
 def test_generate_msa_replay_golden(pkg):
