@@ -527,51 +527,53 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         }
         if (g == 0 && live) { acc_vb += vb; acc_ce += ce; }
       } else {
+        constexpr bool DEVICE_DRAW = MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX;
         float lm[L::V];
-        if (need_post) {
+        if (need_post && !DEVICE_DRAW) {
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            // noise drawn on the device: no host computation to match bit for bit, hardware log2 of the product
-            if constexpr (MODE == DENSE_SAMPLE && NOISE == D3PM_NOISE_PHILOX) lm[v] = fast_log2((f1n[ps % NZ][v] + eps) * f2e[v]) * LN2;
-            else lm[v] = logf(f1n[ps % NZ][v] + eps) + logf(f2e[v]);
-          }
+          for (int v = 0; v < L::V; ++v) lm[v] = logf(f1n[ps % NZ][v] + eps) + logf(f2e[v]);
         }
         if constexpr (MODE == DENSE_POST) {
           float r[L::V];
 #pragma unroll
           for (int v = 0; v < L::V; ++v) r[v] = (t == 0) ? zkeep[ps % NKEEP][v] : lm[v];
           if (live) store_slots<L>(e.out + n * K, g, K, r);
-        } else {   // DENSE_SAMPLE
+        } else if constexpr (DEVICE_DRAW) {
+          // Noise drawn on the device: nothing to match bit for bit, so the draw is one uniform per token and an
+          // inverse CDF over the unnormalised posterior (a_j f2_j) -- no logarithm, no Gumbel transform, one Philox
+          // call per token instead of one per four classes.  t == 0: argmax of the logits, as with explicit noise.
+          int pick;
+          if (t == 0) {
+            float best = -INFINITY;
+            pick = 0x7fffffff;
+#pragma unroll
+            for (int v = 0; v < L::V; ++v) {
+              const int c = L::cls(g, v);
+              const float val = zkeep[ps % NKEEP][v];
+              if (valid(c) && (val > best || pick == 0x7fffffff)) { best = val; pick = c; }
+            }
+            group_argmax<L::G>(best, pick);
+          } else {
+            float w[L::V];
+#pragma unroll
+            for (int v = 0; v < L::V; ++v) w[v] = valid(L::cls(g, v)) ? (f1n[ps % NZ][v] + eps) * f2e[v] : 0.0f;
+            const U4 r = philox4x32_10((uint64_t)n, e.offset, e.seed);
+            const float uu = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+            pick = group_pick<L::G, L::V>(w, g, uu, tok_xt(ps), [](int gg, int vv) { return L::cls(gg, vv); });
+          }
+          if (g == 0 && live) e.sample[n] = pick;
+        } else {   // DENSE_SAMPLE, noise tensor given
           float best = -INFINITY;
           int besti = 0x7fffffff;
           float u[L::V];
-          if constexpr (NOISE != D3PM_NOISE_PHILOX) {
-            if (t > 0) load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
-          }
-          // four classes at a time: one Philox call feeds them, and its words die before the next call
+          if (t > 0) load_slots<L>(e.noise + n * K, g, K, 0.5f, u);
 #pragma unroll
-          for (int h = 0; h < (L::V + 3) / 4; ++h) {
-            if constexpr (NOISE == D3PM_NOISE_PHILOX) {
-              if (t > 0) {
-                const U4 r = philox4x32_10(((uint64_t)n * L::G + g) * ((L::V + 3) / 4) + h, e.offset, e.seed);
-                const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                  if (4 * h + j < L::V) u[4 * h + j] = u01(rr[j]);
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int v = 4 * h + j;
-              if (v >= L::V) continue;
-              const int c = L::cls(g, v);
-              float val;
-              if (t == 0) val = zkeep[ps % NKEEP][v];
-              else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v]
-                              : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v])));
-              if (valid(c) && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
-            }
-            if constexpr (MFMA && NOISE == D3PM_NOISE_PHILOX) __builtin_amdgcn_sched_barrier(0);
+          for (int v = 0; v < L::V; ++v) {
+            const int c = L::cls(g, v);
+            float val;
+            if (t == 0) val = zkeep[ps % NKEEP][v];
+            else val = lm[v] + ((NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]));
+            if (valid(c) && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
           }
           group_argmax<L::G>(best, besti);
           if (g == 0 && live) e.sample[n] = besti;

@@ -360,6 +360,31 @@ def test_graphed_bpd_sweep(pkg):
     assert r2["vbterms"].shape == (B, T) and torch.isfinite(r2["total"]).all()
 
 
+@pytest.mark.parametrize("kind,bits", [("gaussian", 8), ("gaussian", 6), ("uniform", 5)])
+def test_p_sample_device_noise_distribution(pkg, kind, bits):
+    """p_sample with noise drawn on the device (one uniform per token, inverse CDF
+    over the posterior on the dense path): class frequencies over many identical
+    tokens against softmax of the parity-tested posterior logits."""
+    K, T, B, L = 2 ** bits, 50, 8, 8192
+    betas = pkg.generate_betas(1e-3, 0.2, T, "linear") if kind == "gaussian" else pkg.generate_betas(0, 0, T, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.01, device=DEV)
+    gen = torch.Generator().manual_seed(bits)
+    row = (2.0 * torch.randn(K, generator=gen)).to(DEV)
+    logits = row.expand(B, L, 1, 1, K).contiguous()
+    x_t = torch.full((B, L, 1, 1), K // 3, device=DEV)
+    t = torch.tensor([1, 2, 7, 20, 33, 49, 10, 5], dtype=torch.int32, device=DEV)
+    torch.manual_seed(123)
+    s, _ = d.p_sample(lambda x, tt: logits, x=x_t, t=t)
+    post = d.q_posterior_logits(logits[:, :1], x_t[:, :1], t, x_start_logits=True)          # [B,1,1,1,K]
+    P = torch.softmax(post.double(), -1).reshape(B, K).cpu().numpy()
+    for b in range(B):
+        freq = torch.bincount(s[b].flatten().cpu(), minlength=K).numpy() / L
+        tol = 5 * np.sqrt(P[b] * (1 - P[b]) / L) + 2e-4
+        assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,
