@@ -322,6 +322,37 @@ def main():
                               "flops_per_token": 4 * KI * KI, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
         del di, tbi, lgi, dli
 
+    # ---- secondary: the protein-style training loss (D3PMLVBLoss forward + gradient, float64 arithmetic) and the
+    # batched forward corruption of the collaters, B=256 L=512 K=22 n_tokens=24, through the C ABI
+    lvb = None
+    if rank == 0 and not args.no_secondary:
+        BP, LP, KP, LDP = 256, 512, 22, 24
+        x0p = torch.randint(0, KP, (BP, LP), device=dev)
+        tp = torch.randint(2, 500, (BP,), device=dev)
+        xtp = torch.empty_like(x0p)
+        predp = torch.randn(BP, LP, LDP, device=dev)
+        dpp = torch.empty_like(predp)
+        perp = torch.empty(BP, dtype=torch.float64, device=dev)
+        wsbp = lib.d3pm_lvb_loss_workspace(BP, LP, KP)
+        wsp = torch.empty(max(wsbp // 8, 1), dtype=torch.float64, device=dev)
+
+        def lvb_step():
+            check(lib.d3pm_corrupt(ptab.desc(), ptr(x0p), ptr(tp), BP, LP, None, 1, 0, ptr(xtp), None, sp))
+            check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
+                                    1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
+        for _ in range(20):
+            lvb_step()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(100):
+            lvb_step()
+        e1.record()
+        torch.cuda.synchronize()
+        lms = e0.elapsed_time(e1) / 100
+        lvb = {"workload": "protein-style step: batched forward corruption (device noise) + D3PMLVBLoss forward and "
+                           "gradient, B=256 L=512 K=22 n_tokens=24, float64 arithmetic, back-to-back launches",
+               "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3)}
+
     if rank == 0:
         achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
         out = {
@@ -346,6 +377,7 @@ def main():
                                        "graph, path only (frozen logits)",
                                "end_to_end_tiny_denoiser": done_e2e * world / e2e_el},
             "image_k256": dense,
+            "protein_lvb": lvb,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
