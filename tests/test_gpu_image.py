@@ -385,6 +385,52 @@ def test_p_sample_device_noise_distribution(pkg, kind, bits):
         assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
 
 
+def test_raw_ctypes_binding_as_documented(pkg):
+    """The binding a maintainer of the reference would write (plain ctypes, no
+    helper of this package): digests from the float64 tables, then the fused loss
+    and its gradient; equal to the package's own result."""
+    import ctypes as C
+    lib = C.CDLL(pkg._lib.LIB_PATH)
+
+    class TablesF32(C.Structure):
+        _fields_ = [("K", C.c_int), ("T", C.c_int), ("structured", C.c_int), ("eps", C.c_float),
+                    ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p),
+                    ("qbar", C.c_void_p), ("qoneT", C.c_void_p), ("qbarT", C.c_void_p)]
+
+    K, T, B, npos = 32, 500, 256, 40
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    q_mats = d.q_mats.to(DEV)
+    qone = d.transpose_q_onestep_mats.to(DEV).permute(0, 2, 1)
+    dg_bar, dg_one = torch.empty(T, 4, K, device=DEV), torch.empty(T, 4, K, device=DEV)
+    viol = torch.zeros(2, dtype=torch.int32, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    for tab, dg, off in ((q_mats, dg_bar, 0), (qone, dg_one, 4)):
+        rc = lib.d3pm_digest_f32(C.c_void_p(tab.data_ptr()), *map(C.c_long, tab.stride()), T, K, C.c_float(1e-6),
+                                 C.c_void_p(dg.data_ptr()), C.c_void_p(viol.data_ptr() + off), C.c_void_p(s))
+        assert rc == 0
+    assert viol.tolist() == [0, 0]
+    tb = TablesF32(K, T, 1, 1e-6, dg_bar.data_ptr(), dg_one.data_ptr(), None, None, None)
+    gen = torch.Generator().manual_seed(4)
+    x0 = torch.randint(0, K, (B, npos, 1, 1), generator=gen).to(DEV)
+    t = torch.randint(0, T, (B,), generator=gen, dtype=torch.int32).to(DEV)
+    x_t = d.q_sample(x0, t)
+    logits = torch.randn(B, npos, 1, 1, K, generator=gen).to(DEV)
+    loss, dlogits = torch.empty(B, device=DEV), torch.empty_like(logits)
+    lib.d3pm_last_error.restype = C.c_char_p
+    rc = lib.d3pm_hybrid_loss(C.byref(tb), C.c_void_p(logits.data_ptr()), C.c_long(K),
+                              C.c_void_p(x0.data_ptr()), 8, C.c_void_p(x_t.data_ptr()), 8, C.c_void_p(t.data_ptr()), 4,
+                              B, C.c_long(npos), 2, C.c_float(0.001), C.c_float(1.0 / B), None,
+                              None, None, C.c_void_p(loss.data_ptr()), C.c_void_p(dlogits.data_ptr()),
+                              None, None, C.c_uint64(0), None, C.c_size_t(0), C.c_void_p(s))
+    assert rc == 0, lib.d3pm_last_error()
+    lg = logits.clone().requires_grad_(True)
+    ref = d._fused(lg, x0, x_t, t, "hybrid")
+    ref.mean().backward()
+    assert torch.equal(loss, ref) and torch.equal(dlogits, lg.grad)
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,
