@@ -468,6 +468,15 @@ class DiscreteDiffusion:
         per batch element, which lengthens that kernel by ~2.8 us at B = 256);
         gradients -- of the batch mean either way -- are accumulated into whatever
         the logits depend on when ``backward`` is true."""
+        corrupted = self.corrupt_step(x_start=x_start, rng=rng, device_mean=device_mean)
+        return self.loss_step(model_fn, x_start=x_start, corrupted=corrupted, backward=backward)
+
+    def corrupt_step(self, *, x_start, rng=None, offset=0, device_mean=False):
+        """First half of ``training_step``: one launch drawing the timesteps and the
+        noisy tokens.  ``rng=(seed, counter)``: Philox stream offset = ``offset`` + the
+        counter's value when the kernel runs.  It depends on nothing but ``x_start`` and
+        the counter, so the next step's corruption can run (on another stream) while
+        this step's denoiser and loss do.  Returns the dict ``loss_step`` takes."""
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         if self.model_prediction != "x_start":
@@ -477,7 +486,7 @@ class DiscreteDiffusion:
         tb = self.tables()
         B, npos = self._dims(x0)
         dev = x0.device
-        seed = off = 0
+        seed, off = 0, int(offset)
         counter = None
         if rng is not None:
             seed, counter = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, rng[1]
@@ -486,10 +495,22 @@ class DiscreteDiffusion:
             seed, off = _philox_ticket(dev)
         t = torch.empty(B, dtype=torch.int32, device=dev)
         x_t = torch.empty(x0.shape, dtype=torch.int64, device=dev)
-        mean = torch.empty((), dtype=torch.float32, device=dev) if device_mean else None   # zeroed by the first launch
+        mean = torch.empty((), dtype=torch.float32, device=dev) if device_mean else None   # zeroed by this launch
         with torch.cuda.device(dev):
             check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(mean),
                                            ptr(t), ptr(x_t), stream_ptr()))
+        return {"t": t, "x_t": x_t, "mean": mean, "counter": counter}
+
+    def loss_step(self, model_fn, *, x_start, corrupted, backward=True, advance=4):
+        """Second half of ``training_step``: the denoiser, then one launch for the
+        per-example losses and d mean / d logits, handed to autograd.  ``advance``:
+        what the loss kernel adds to the Philox counter of ``corrupt_step`` (4 = one
+        step; a pipelined sequence of n steps passes 0 for all but the last, 4 n there)."""
+        x0 = _as_tokens(x_start)
+        tb = self.tables()
+        B, npos = self._dims(x0)
+        dev = x0.device
+        t, x_t, mean, counter = corrupted["t"], corrupted["x_t"], corrupted["mean"], corrupted["counter"]
         pred = self._denoiser_logits(model_fn, x_t, t)
         assert pred.shape == x0.shape + (tb.K,), pred.shape
         lg = pred.detach().contiguous()
@@ -504,14 +525,14 @@ class DiscreteDiffusion:
             check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
                                        _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0),
                                        float(np.float32(1.0) / np.float32(max(B, 1))), None, None, None, ptr(losses),
-                                       ptr(dl), ptr(mean), ptr(counter), 4 if counter is not None else 0, ptr(ws),
-                                       ws_bytes, stream_ptr()))
+                                       ptr(dl), ptr(mean), ptr(counter), int(advance) if counter is not None else 0,
+                                       ptr(ws), ws_bytes, stream_ptr()))
         if want_grad:
             holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
             del dl
             torch.autograd.backward(_Handoff.apply(pred, holder), self._unit(dev))
         out = StepResult(losses=losses, t=t, x_t=x_t)
-        if device_mean:
+        if mean is not None:
             out["loss"] = mean
         return out
 
