@@ -69,8 +69,7 @@ class GraphedTrainingStep:
 
     ``steps`` > 1 captures that many consecutive steps in one graph (a replay then
     costs one host-side graph launch, ~19 us, for all of them: with one step of
-    ~16 us of GPU work per graph the host is the bound), with the corruption
-    launches on a second captured stream so that they overlap the preceding step.  ``x_start`` is then
+    ~16 us of GPU work per graph the host is the bound).  ``x_start`` is then
     either one batch buffer read by every step or a sequence of ``steps`` buffers
     (a ring of pre-staged batches); ``params``' gradients are cleared before each
     captured step, so after a replay they hold the last step's gradient --
@@ -96,32 +95,11 @@ class GraphedTrainingStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self.outs = []
-        if steps == 1:
-            with torch.cuda.graph(self.graph):
-                self.outs.append(self._body(self.x_start))
-        else:
-            # The corruption launches depend only on the data and on the Philox counter, which the last loss launch of
-            # the graph advances for all steps at once: they are captured on a second stream, so that step j + 1's
-            # corruption runs beside step j's denoiser and loss (a prefetch, as a data loader would do it).
-            prefetch = torch.cuda.Stream(device=dev)
-            rng = (self.seed, self.counter)
-            with torch.cuda.graph(self.graph):
-                main = torch.cuda.current_stream(dev)
-                prefetch.wait_stream(main)
-                corrupted, ready = [], []
-                with torch.cuda.stream(prefetch):
-                    for j, x in enumerate(self.batches):
-                        corrupted.append(diffusion.corrupt_step(x_start=x, rng=rng, offset=4 * j))
-                        ev = torch.cuda.Event()
-                        ev.record(prefetch)
-                        ready.append(ev)
-                for j, x in enumerate(self.batches):
-                    for p in params:
-                        p.grad = None
-                    main.wait_event(ready[j])
-                    self.outs.append(diffusion.loss_step(model_fn, x_start=x, corrupted=corrupted[j],
-                                                         advance=4 * steps if j == steps - 1 else 0))
-                main.wait_stream(prefetch)
+        with torch.cuda.graph(self.graph):
+            for x in self.batches:
+                for p in params:
+                    p.grad = None
+                self.outs.append(self._body(x))
         self.out = self.outs[-1]
 
     def _body(self, x):
