@@ -81,6 +81,80 @@ def sample_and_save(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, s
     return strings
 
 
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n_total items for `rank`; sizes differ by at most one."""
+    per, rem = divmod(n_total, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def gather_token_shards(local: torch.Tensor, group=None):
+    """All ranks' [n_r, L] token shards, concatenated in rank order, on every rank
+    (uint8 on the wire: K <= 256).  Ragged shards are padded to the largest.  Without
+    an initialised process group the local shard is returned."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
+    sizes = [int(x.item()) for x in sizes]
+    padded = torch.zeros((max(sizes), local.shape[1]), dtype=torch.uint8, device=local.device)
+    padded[:local.shape[0]] = local.to(torch.uint8)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)]).to(local.dtype)
+
+
+def sample_and_save_sharded(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, seq_len, device, batch_size=1024,
+                            seed=0, graph=True):
+    """``sample_and_save`` (generate.py:118-130) over all ranks of the default
+    process group: every rank generates its contiguous share of the `num_seqs`
+    sequences in sub-batches of `batch_size` from its own Philox stream
+    (seed + rank), with no communication until the final gather; rank 0 writes the
+    FASTA file in the reference's format.  ``graph``: replay the T-1 step loop of a
+    sub-batch as one HIP graph (``model`` must be capturable).  Returns the strings
+    on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from ..graphs import GraphedReverseSampler
+    dist_on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
+    lo, hi = shard_range(num_seqs, rank, world)
+    device = torch.device(device)
+    tables = protein_tables(Q, Q_bar, device=device)
+    model.eval()
+    out = torch.empty((hi - lo, seq_len), dtype=torch.long, device=device)
+    sub = max(1, min(batch_size, hi - lo))
+    done = 0
+    if graph and hi > lo:
+        smp = GraphedReverseSampler(tables, model, sub, seq_len, timesteps, device, seed=seed + rank)
+        while done < hi - lo:                      # the last sub-batch may overshoot: surplus rows are dropped
+            n = min(sub, hi - lo - done)
+            out[done:done + n] = smp.sample()[:n]
+            done += n
+    else:
+        steps = list(range(timesteps - 1, 0, -1))
+        counter = torch.zeros(1, dtype=torch.int64, device=device)
+        with torch.no_grad():
+            while done < hi - lo:
+                n = min(sub, hi - lo - done)
+                x = torch.randint(0, tokenizer.K, (n, seq_len), device=device)
+                for i, t in enumerate(steps):
+                    tt = torch.full((n,), t, dtype=torch.long, device=device)
+                    x = reverse_step(tables, model(x, tt), x, tt, rng=(seed + rank, 4 * i, counter))
+                counter.add_(4 * len(steps))
+                out[done:done + n] = x
+                done += n
+    tokens = gather_token_shards(out)
+    if rank != 0:
+        return None
+    strings = [tokenizer.untokenize(s) for s in tokens.cpu()]
+    with open(out_path + "generated_samples_string.fasta", "w") as f:
+        for i, s in enumerate(strings):
+            f.write(">SEQUENCE_" + str(i) + "\n" + str(s) + "\n")
+    return strings
+
+
 def generate_msa_d3pm(model, batch_size, n_sequences, seq_length, device, timesteps=500, penalty_value=0, Q_bar=None,
                       Q=None, tokenizer=None, start_query=True, query_sequence=None, x_init=None, noise_fn=None):
     """Sample `batch_size` MSAs of `n_sequences` x `seq_length` tokens by T-1 reverse

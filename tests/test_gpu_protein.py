@@ -333,3 +333,25 @@ def test_graphed_reverse_sampler(pkg):
         tt = torch.full((B,), t, dtype=torch.long, device=DEV)
         s = reverse_step(tb, model(s, tt), s, tt, rng=(9, 4 * i, c))
     assert torch.equal(s, a)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_sample_and_save_sharded_single_rank(pkg, tmp_path, graph):
+    """The rank-sharded sampling driver without a process group: 37 sequences in
+    sub-batches of 16 (the last one partial), FASTA in the reference's format."""
+    from d3pm_amd.protein_generation.generate import sample_and_save_sharded
+    tok = pkg.Tokenizer()
+    T, L = 12, 21
+    Qb, Qt = tok.q_uniform_schedule(num_steps=T, device=DEV)
+    emb = torch.randn(22, 24, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    class Tiny(torch.nn.Module):
+        def forward(self, x, t):
+            return emb[x] + 0.01 * t[:, None, None].float()
+
+    out = str(tmp_path) + "/"
+    strings = sample_and_save_sharded(out, 37, Tiny(), tok, Qt, Qb, T, L, DEV, batch_size=16, seed=5, graph=graph)
+    assert len(strings) == 37 and all(len(s) == L and set(s) <= set("ACDEFGHIKLMNPQRSTVWYX-") for s in strings)
+    lines = open(out + "generated_samples_string.fasta").read().split("\n")
+    assert lines[0] == ">SEQUENCE_0" and lines[1] == strings[0] and lines[72] == ">SEQUENCE_36" and lines[74] == ""
+    assert len(set(strings)) > 30          # independent draws
