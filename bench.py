@@ -174,13 +174,16 @@ def main():
         tok = d3pm_amd.Tokenizer()
         Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
         ptab = protein_tables(Qt, Qb)
+        rem = n_local % sub                        # the shard's last, partial sub-batch gets a graph of its own
         frozen = torch.randn(sub, 263, 22, device=dev)
         emb = torch.randn(22, 64, device=dev) * 0.5
         tvec = torch.randn(501, 64, device=dev) * 0.1
         head = torch.randn(64, 24, device=dev) * 0.3
         tiny = lambda x, tt: (emb[x] + tvec[tt][:, None, :]) @ head
-        samplers = [d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, sub, 263, 500, dev, seed=77 + rank)
-                    for fn in ((lambda x, tt: frozen), tiny)]     # path only / with a tiny denoiser
+        frozen_fn = lambda x, tt: frozen[:x.shape[0]]
+        # [path only, with a tiny denoiser] x [full sub-batch, remainder]
+        samplers = [[d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, nb, 263, 500, dev, seed=77 + rank + 1000 * k)
+                     for k, nb in enumerate((sub, rem)) if nb > 0] for fn in (frozen_fn, tiny)]
     torch.cuda.synchronize()
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
@@ -261,17 +264,22 @@ def main():
     done = done_e2e = 0
     rev_el = e2e_el = 1.0
     if not args.no_secondary:
-        def run_sampler(smp):
-            """10 000 sequences through the 499-step loop, one HIP graph replay per sub-batch."""
-            smp.sample()
+        def run_sampler(smps):
+            """This rank's share of the 10 000 sequences through the 499-step loop, one HIP graph replay per
+            sub-batch (the last one partial)."""
+            for smp in smps:
+                smp.sample()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             r0 = time.perf_counter()
             n = 0
-            while n < n_local:
-                smp.sample()
+            for _ in range(n_local // sub):
+                smps[0].sample()
                 n += sub
+            if rem:
+                smps[1].sample()
+                n += rem
             torch.cuda.synchronize()
             el = time.perf_counter() - r0
             if world > 1:
