@@ -327,15 +327,16 @@ class DiscreteDiffusion:
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
-    def p_sample(self, model_fn, *, x, t, noise=None, noise_kind: str = "uniform"):
-        """One reverse step (:384-403): (sample int64, softmax(pred_x_start))."""
+    def p_sample(self, model_fn, *, x, t, noise=None, noise_kind: str = "uniform", rng=None):
+        """One reverse step (:384-403): (sample int64, softmax(pred_x_start)).
+        ``rng=(seed, counter[, offset])`` as in ``q_sample`` (device noise)."""
         assert t.shape == (x.shape[0],)
         pred = self._denoiser_logits(model_fn, x, t)
         if self.model_prediction != "x_start":
             raise NotImplementedError(self.model_prediction)
-        return self._p_sample_from_logits(pred, x, t, noise, noise_kind, want_probs=True)
+        return self._p_sample_from_logits(pred, x, t, noise, noise_kind, want_probs=True, rng=rng)
 
-    def _p_sample_from_logits(self, pred, x, t, noise, noise_kind, want_probs):
+    def _p_sample_from_logits(self, pred, x, t, noise, noise_kind, want_probs, rng=None):
         K = self.num_pixel_vals
         lg = pred.contiguous().float()
         xt, t = _as_tokens(x), _as_tokens(t)
@@ -344,9 +345,15 @@ class DiscreteDiffusion:
         tb = self.tables()
         B, npos = self._dims(xt)
         seed = off = 0
+        off_dev = None
         if noise is None:
             kind = _lib.NOISE_PHILOX
-            seed, off = _philox_ticket(xt.device)
+            if rng is not None:
+                seed, off_dev = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, rng[1]
+                off = int(rng[2]) if len(rng) > 2 else 0
+                assert off_dev.dtype == torch.int64 and off_dev.is_cuda
+            else:
+                seed, off = _philox_ticket(xt.device)
         else:
             assert noise.shape == lg.shape, noise.shape
             kind = _lib.NOISE[noise_kind]
@@ -355,16 +362,21 @@ class DiscreteDiffusion:
         probs = torch.empty_like(lg) if want_probs else None
         with torch.cuda.device(xt.device):
             check(lib.d3pm_p_sample(tb.desc(), ptr(lg), K, ptr(xt), tok_bytes(xt), ptr(t), tok_bytes(t), B, npos,
-                                    ptr(noise), kind, seed, off, None, ptr(sample), ptr(probs), stream_ptr()))
+                                    ptr(noise), kind, seed, off, ptr(off_dev), ptr(sample), ptr(probs), stream_ptr()))
         return sample, probs
 
     @torch.no_grad()
     def p_sample_loop(self, model_fn, *, shape, num_timesteps=None, return_x_init=False, return_im_steps=False,
-                      save_interval=None):
-        """Ancestral sampling (:405-458); noise is drawn on device per step."""
+                      save_interval=None, x_init=None, rng=None):
+        """Ancestral sampling (:405-458); noise is drawn on device per step.
+        ``x_init`` (optional) replaces the draw of x_T; ``rng=(seed, counter)``: step
+        i uses Philox offset 4 i + the device counter (``graphs.GraphedPSampleLoop``
+        captures the whole loop that way)."""
         shape = tuple(shape)
         K = self.num_pixel_vals
-        if self.transition_mat_type in ("gaussian", "uniform"):
+        if x_init is not None:
+            assert tuple(x_init.shape) == shape, (x_init.shape, shape)
+        elif self.transition_mat_type in ("gaussian", "uniform"):
             x_init = torch.randint(low=0, high=K, size=shape, device=self.device)
         elif self.transition_mat_type == "absorbing":
             x_init = torch.full(size=shape, fill_value=K // 2, dtype=torch.int32, device=self.device)
@@ -378,7 +390,8 @@ class DiscreteDiffusion:
         for i in range(num_timesteps):
             t = torch.full([shape[0]], self.num_timesteps - 1 - i, device=self.device)
             pred = self._denoiser_logits(model_fn, x, t)
-            x, _ = self._p_sample_from_logits(pred, x, t, None, "uniform", want_probs=False)
+            x, _ = self._p_sample_from_logits(pred, x, t, None, "uniform", want_probs=False,
+                                              rng=None if rng is None else (rng[0], rng[1], 4 * i))
             if keep is not None and (i + 1) % save_interval == 0:
                 keep.append(x.detach().cpu())
         if keep is not None:

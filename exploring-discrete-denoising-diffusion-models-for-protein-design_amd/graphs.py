@@ -193,3 +193,42 @@ class GraphedBpdSweep:
         self.counter.add_(self.stride)
         self.graph.replay()
         return self.out
+
+
+class GraphedPSampleLoop:
+    """``DiscreteDiffusion.p_sample_loop`` (:405-458) for a fixed shape -- the
+    denoiser call and the reverse step of every timestep -- captured into one HIP
+    graph.  ``sample()`` draws x_T (uniform tokens, or K // 2 for absorbing
+    transitions) unless ``x_init`` is given, advances the device Philox counter so
+    that every replay draws fresh noise, replays, and returns the static result
+    tensor (clone it before the next call).  ``model_fn`` must be capturable."""
+
+    def __init__(self, diffusion, model_fn, shape, seed: int = 0, num_timesteps=None):
+        self.diffusion, self.model_fn, self.shape = diffusion, model_fn, tuple(shape)
+        dev = torch.device(diffusion.device)
+        diffusion.tables()                                   # set-up syncs are not capturable
+        self.steps = diffusion.num_timesteps if num_timesteps is None else num_timesteps
+        self.x = torch.zeros(self.shape, dtype=torch.int64, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed = int(seed)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                        # one untimed step outside the capture
+            diffusion.p_sample_loop(model_fn, shape=self.shape, num_timesteps=1, x_init=self.x,
+                                    rng=(self.seed, self.counter))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = diffusion.p_sample_loop(model_fn, shape=self.shape, num_timesteps=self.steps, x_init=self.x,
+                                               rng=(self.seed, self.counter))
+
+    def sample(self, x_init=None):
+        if x_init is not None:
+            self.x.copy_(x_init)
+        elif self.diffusion.transition_mat_type == "absorbing":
+            self.x.fill_(self.diffusion.num_pixel_vals // 2)
+        else:
+            self.x.random_(0, self.diffusion.num_pixel_vals)
+        self.counter.add_(4 * self.steps)
+        self.graph.replay()
+        return self.out

@@ -431,6 +431,33 @@ def test_raw_ctypes_binding_as_documented(pkg):
     assert torch.equal(loss, ref) and torch.equal(dlogits, lg.grad)
 
 
+@pytest.mark.parametrize("kind,bits", [("uniform", 5), ("gaussian", 8), ("absorbing", 4)])
+def test_graphed_p_sample_loop(pkg, kind, bits):
+    """The whole p_sample_loop replayed as one HIP graph equals the eager loop on
+    the same Philox stream and start tokens; the next replay draws different noise."""
+    from d3pm_amd.graphs import GraphedPSampleLoop
+    K, T, shape = 2 ** bits, 12, (3, 6, 5, 1)
+    betas = pkg.generate_betas(1e-3, 0.3, T, "linear") if kind == "gaussian" else pkg.generate_betas(0, 0, T, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.001, device=DEV)
+    gen = torch.Generator().manual_seed(bits)
+    emb = torch.randn(K, K, generator=gen).to(DEV)
+    temb = torch.randn(T, K, generator=gen).to(DEV)
+    model = lambda x, t: emb[x.long()] + temb[t.long()][:, None, None, None, :]
+    loop = GraphedPSampleLoop(d, model, shape, seed=21)
+    x_init = torch.randint(0, K, shape, generator=gen).to(DEV)
+    r1 = loop.sample(x_init).clone()
+    counter = torch.full((1,), 4 * T, dtype=torch.int64, device=DEV)      # the counter's value in that replay
+    eager = d.p_sample_loop(model, shape=shape, x_init=x_init, rng=(21, counter))
+    assert torch.equal(r1, eager) and r1.dtype == torch.int64 and r1.shape == shape
+    assert int(r1.min()) >= 0 and int(r1.max()) < K
+    r2 = loop.sample(x_init).clone()
+    assert not torch.equal(r1, r2)
+    r3 = loop.sample()                                  # x_T drawn by the sampler
+    assert r3.shape == shape
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,
