@@ -1064,7 +1064,7 @@ extern "C" int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok
     hipLaunchKernelGGL(k_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_prior");
     hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s,
-                       LossOut{out, nullptr, nullptr, part, nullptr, 0}, B,
+                       LossOut{out, nullptr, nullptr, part, nullptr, 0, nullptr, 0.0f}, B,
                        a.chunks, npos, D3PM_LOSS_KL, 0.0f, 1.0f / LN2);
     D3PM_LAUNCH_CHECK("k_loss_finalize");
     return D3PM_OK;
