@@ -661,24 +661,33 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
         const int c = L::cls(g, v);
         if (c < K && (z[v] > best || besti == 0x7fffffff)) { best = z[v]; besti = c; }
       }
-    } else {
+    } else if constexpr (NOISE == D3PM_NOISE_PHILOX) {
+      // noise drawn on the device: nothing to match bit for bit, so one uniform per token and an inverse CDF over the
+      // unnormalised posterior (a_j + eps)(f2_j + eps) -- no logarithm, no Gumbel transform
       const int xt = load_tok(a.xt, n, a.xt_bytes);
-      const float l1d = dg(a.tb.qone_digest, t, 2, K)[xt], l1o = dg(a.tb.qone_digest, t, 3, K)[xt];
-      float u[L::V];
-      if constexpr (NOISE == D3PM_NOISE_PHILOX) {
-        const U4 r = philox4x32_10((uint64_t)n * L::G + g, offset, seed);
-        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) u[v] = u01(rr[v]);
-      } else {
-        load_slots<L>(noise + n * K, g, K, 0.5f, u);
-      }
+      const float a_d = dg(a.tb.qone_digest, t, 0, K)[xt] + eps, a_o = dg(a.tb.qone_digest, t, 1, K)[xt] + eps;
+      float w[L::V];
 #pragma unroll
       for (int v = 0; v < L::V; ++v) {
         const int c = L::cls(g, v);
         const float f2 = fmaf(P.bd[v] - P.bo[v], pi[v], P.bo[v]);
-        const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v]
-                          : (NOISE == D3PM_NOISE_PHILOX ? gumbel_from_uniform_fast(u[v]) : gumbel_from_uniform(u[v]));
+        w[v] = c < K ? ((c == xt) ? a_d : a_o) * (f2 + eps) : 0.0f;
+      }
+      const U4 r = philox4x32_10((uint64_t)n, offset, seed);
+      const float uu = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+      besti = group_pick<L::G, L::V>(w, g, uu, xt, [](int gg, int vv) { return L::cls(gg, vv); });
+      if (g == 0) sample[n] = besti;
+      continue;
+    } else {
+      const int xt = load_tok(a.xt, n, a.xt_bytes);
+      const float l1d = dg(a.tb.qone_digest, t, 2, K)[xt], l1o = dg(a.tb.qone_digest, t, 3, K)[xt];
+      float u[L::V];
+      load_slots<L>(noise + n * K, g, K, 0.5f, u);
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const int c = L::cls(g, v);
+        const float f2 = fmaf(P.bd[v] - P.bo[v], pi[v], P.bo[v]);
+        const float gum = (NOISE == D3PM_NOISE_GUMBEL) ? u[v] : gumbel_from_uniform(u[v]);
         const float val = (((c == xt) ? l1d : l1o) + logf(f2 + eps)) + gum;
         if (c < K && (val > best || besti == 0x7fffffff)) { best = val; besti = c; }
       }
