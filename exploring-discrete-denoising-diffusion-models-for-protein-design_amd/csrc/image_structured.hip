@@ -651,7 +651,21 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
     float z[L::V], pi[L::V], zmax, zsum;
     load_slots<L>(logits + n * ld, g, K, -INFINITY, z);
     const bool want_pi = (t > 0) || probs;
-    if (want_pi) group_softmax<L>(z, pi, zmax, zsum);
+    if (NOISE == D3PM_NOISE_PHILOX && !probs) {
+      // device noise and no probabilities asked for: nothing is compared bit for bit, hardware exp2 / rcp
+      if (want_pi) {
+        float m = z[0];
+#pragma unroll
+        for (int v = 1; v < L::V; ++v) m = fmaxf(m, z[v]);
+        m = group_max<L::G>(m);
+        float ssum = 0;
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((z[v] - m) * LOG2E); ssum += pi[v]; }
+        const float inv = fast_rcp(group_sum<L::G>(ssum));
+#pragma unroll
+        for (int v = 0; v < L::V; ++v) pi[v] *= inv;
+      }
+    } else if (want_pi) group_softmax<L>(z, pi, zmax, zsum);
     if (probs) store_slots<L>(probs + n * K, g, K, pi);
     float best = -INFINITY;
     int besti = 0x7fffffff;

@@ -379,10 +379,14 @@ def test_p_sample_device_noise_distribution(pkg, kind, bits):
     s, _ = d.p_sample(lambda x, tt: logits, x=x_t, t=t)
     post = d.q_posterior_logits(logits[:, :1], x_t[:, :1], t, x_start_logits=True)          # [B,1,1,1,K]
     P = torch.softmax(post.double(), -1).reshape(B, K).cpu().numpy()
-    for b in range(B):
-        freq = torch.bincount(s[b].flatten().cpu(), minlength=K).numpy() / L
-        tol = 5 * np.sqrt(P[b] * (1 - P[b]) / L) + 2e-4
-        assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
+    # the sampling loop's call shape (no probabilities requested) takes the hardware exp2 / rcp softmax
+    s_loop, none = d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False)
+    assert none is None
+    for draws in (s, s_loop):
+        for b in range(B):
+            freq = torch.bincount(draws[b].flatten().cpu(), minlength=K).numpy() / L
+            tol = 5 * np.sqrt(P[b] * (1 - P[b]) / L) + 2e-4
+            assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
 
 
 def test_raw_ctypes_binding_as_documented(pkg):
