@@ -104,7 +104,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # the process group (RCCL) is only needed for N > 1; D3PM_BENCH_FORCE_PG=1 creates it for a single rank too, to
+    # rehearse the barrier / all-reduce calls of the multi-GPU run on a one-GPU box (launch through torch.distributed.run)
+    use_pg = world > 1 or bool(os.environ.get("D3PM_BENCH_FORCE_PG"))
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
@@ -185,7 +188,7 @@ def main():
         samplers = [[d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, nb, 263, 500, dev, seed=77 + rank + 1000 * k)
                      for k, nb in enumerate((sub, rem)) if nb > 0] for fn in (frozen_fn, tiny)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.init_process_group("nccl", device_id=dev)
 
     # bring the GPU to its sustained clocks first (a step is ~20 us: a short run would otherwise be timed on a
@@ -196,17 +199,17 @@ def main():
         torch.cuda.synchronize()
     run_steps(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -270,7 +273,7 @@ def main():
             for smp in smps:
                 smp.sample()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_pg:
                 dist.barrier()
             r0 = time.perf_counter()
             n = 0
@@ -282,7 +285,7 @@ def main():
                 n += rem
             torch.cuda.synchronize()
             el = time.perf_counter() - r0
-            if world > 1:
+            if use_pg:
                 tt_ = torch.tensor([el], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                 el = float(tt_.item())
@@ -390,7 +393,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 
