@@ -2,23 +2,29 @@
 """Benchmark of the D3PM hot path on MI355X.
 
 One step = one pass of the hot path over one synthetic batch of the protein
-configuration (B=256, L=512, K=32, T=500, uniform transitions): forward
-corruption `q_sample` (on-device Philox noise) + the fused posterior / hybrid
-loss forward+backward kernel producing d loss / d logits for `.mean()` + the
-backward hand-off of the autograd node (a rescale launch that exits early).
-The denoiser is excluded: its logits are a pre-filled device tensor.
+configuration (B=256, L=512, K=32, T=500, uniform transitions): timestep draw +
+forward corruption `q_sample` (on-device Philox noise) + the fused posterior /
+hybrid loss forward+backward kernel producing per-example losses and
+d mean / d logits, handed to autograd.  The denoiser is excluded: its logits are
+a pre-filled device tensor.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one process per GPU (torchrun env); the batch is
-sharded with no data-path collective (weak scaling: every rank runs the full
-per-GPU batch).  Rank 0 prints one JSON line.
+With N > 1 and no torchrun environment the script starts N fresh child processes
+itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before it
+touches a GPU, relays rank 0's JSON line and exits with the first non-zero child
+status; under `python -m torch.distributed.run` it is one of the ranks.  The
+batch is sharded with no data-path collective (weak scaling: every rank runs the
+full per-GPU batch); the process group (RCCL) carries the barriers and the
+max-over-ranks time only.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,30 +37,119 @@ B, L, K, T = 256, 512, 32, 500
 LAMBDA = 0.001
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 BYTES_PER_TOKEN = 8 * K + 16   # logits in + dlogits out (float32) + x0 + x_t (int64)
-# HBM bytes per launch of the fused loss kernel from the PMC passes kept under profiles/
-# (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), or None when no profile is committed.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
+MIN_TIMED_S = 5e-3             # the timed region lasts at least this long whatever --steps says
+N_SEQS, SEQ_LEN, K_PROT, T_PROT = 10000, 263, 22, 500
+SUB_BATCH = 1250               # reverse sampling: sequences per graph replay (10 000 / 8 GPUs)
+# HBM bytes per launch of a kernel from the PMC passes kept under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+# correction); the newest committed profile that names the kernel wins.  Not measured by this run: counters need a
+# rocprofv3 pass of their own.
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json")]
 
 
-def measured_traffic():
-    try:
-        prof = json.load(open(TRAFFIC_FILE))
+def measured_traffic(kernel: str, must_contain: str = ""):
+    for path in TRAFFIC_FILES:
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
         for name, ctr in prof.items():
-            if "k_hybrid_loss" in name and "true>(" in name[name.index("k_hybrid_loss"):] \
+            if kernel in name and must_contain in name[name.index(kernel):] \
                     and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                return (2 * ctr["FETCH_SIZE"]["mean_per_launch"] + ctr["WRITE_SIZE"]["mean_per_launch"]) * 1024
-    except (OSError, ValueError, KeyError):
-        pass
+                return {"bytes": (2 * ctr["FETCH_SIZE"]["mean_per_launch"] + ctr["WRITE_SIZE"]["mean_per_launch"]) * 1024,
+                        "source": os.path.relpath(path, ROOT)}
     return None
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """The CPU oracle (a restatement of the reference's eager PyTorch path: float64
-    tables cast per call, every [N,K] intermediate materialised, autograd
-    backward) timed on this host's cores on the same workload."""
+# ------------------------------------------------------------------ N-rank launch
+def spawn_plan(n: int, master_port: int, base_env=None):
+    """Environment of each of the n ranks `bench.py --gpus n` starts: one process per GPU of this node."""
+    base = dict(os.environ if base_env is None else base_env)
+    plan = []
+    for r in range(n):
+        env = dict(base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        plan.append(env)
+    return plan
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start n fresh children of this script (the parent has made no GPU call), relay rank 0's stdout, return the
+    first non-zero exit status (0 if every rank succeeded).  A failing rank ends the others."""
+    import threading
+    plan = spawn_plan(n, _free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL)
+             for r, env in enumerate(plan)]
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                 # exactly the children started above, by PID
+                    procs[q].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------ CPU baselines
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(step, budget_s: float, warm: int = 3, blocks: int = 10):
+    """3 untimed calls, then the median over 10 timed blocks; a block repeats the call so that the ten blocks
+    together take about `budget_s`."""
+    for _ in range(warm):
+        step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    per_block = max(1, int(budget_s / blocks / max(one, 1e-6)))
+    times = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(per_block):
+            step()
+        times.append((time.perf_counter() - t0) / per_block)
+    times.sort()
+    return 0.5 * (times[blocks // 2 - 1] + times[blocks // 2]), per_block * blocks
+
+
+def cpu_baselines(budget_s: float = 10.0):
+    """The CPU oracle (a restatement of the reference's eager PyTorch path: float64 tables cast per call, every
+    [N,K] intermediate materialised, per-sequence Python loops in the protein style, autograd backward) timed on
+    this host's cores: the headline step, one protein-style loss step, one reverse-sampling step."""
     import torch
     from oracle import image_style as im
+    from oracle import protein_style as pr
     cores = torch.get_num_threads()
+    host = f"{_cpu_model()}, torch {torch.__version__} CPU, {cores} threads; 3 warm-ups, median of 10 blocks"
     g = torch.Generator().manual_seed(0)
     betas = im.make_betas(0.0, 0.0, T, "jsd")
     p = im.build_process(betas, "uniform", 5, None, hybrid_coeff=LAMBDA)
@@ -68,155 +163,210 @@ def cpu_baseline(budget_s: float = 12.0):
         logits.grad = None
         loss.mean().backward()
 
-    step()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 200:
-            break
-    return {"value": B * L * n / el, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of the same workload (B={B}, L={L}, K={K}, T={T}, uniform, hybrid loss fwd+bwd "
-                      f"incl. q_sample and noise draw) in {el:.1f} s, torch {torch.__version__} CPU, {cores} threads"}
+    med, n = _median_time(step, budget_s)
+    head = {"value": B * L / med, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same workload (B={B}, L={L}, K={K}, T={T}, uniform, hybrid loss fwd+bwd incl. "
+                      f"q_sample and noise draw), median {med * 1e3:.1f} ms per step; {host}"}
+
+    # protein-style loss: D3PMLVBLoss forward + backward on a 64-sequence slice of the B=256 L=512 n_tokens=24 batch
+    BS, LP, LDP = 64, 512, 24
+    qb, qt = pr.uniform_tables(K_PROT, T_PROT, "sohl-dickstein")
+    tg = torch.randint(0, K_PROT, (BS, LP), generator=g)
+    src = torch.randint(0, K_PROT, (BS, LP), generator=g)
+    tsp = torch.randint(2, T_PROT, (BS,), generator=g)
+    pred = torch.randn(BS, LP, LDP, generator=g, requires_grad=True)
+    src_oh, tg_oh = pr.one_hot(src, K_PROT), pr.one_hot(tg, K_PROT)
+
+    def lvb_step():
+        pred.grad = None
+        pr.lvb(src_oh, None, pred, tg, tg_oh, tsp, qt, qb, K=K_PROT, tmax=T_PROT).backward()
+
+    med_l, n_l = _median_time(lvb_step, budget_s)
+    lvb = {"value": BS * LP / med_l, "unit": "tokens/s", "cores": cores, "kind": "port",
+           "sample": f"{n_l} steps of D3PMLVBLoss forward + backward on a {BS}-sequence slice (L={LP}, K={K_PROT}, "
+                     f"n_tokens={LDP}, 2 <= t < {T_PROT}), median {med_l * 1e3:.1f} ms per step; {host}"}
+
+    # reverse sampling: one step of generate_d3pm on a 256-sequence slice, extrapolated to the 499 steps
+    BR = 256
+    xr = torch.randint(0, K_PROT, (BR, SEQ_LEN), generator=g)
+    lgr = torch.randn(BR, SEQ_LEN, K_PROT, generator=g)
+
+    def rev_step():
+        e = torch.empty(BR, SEQ_LEN, K_PROT, dtype=torch.float64).exponential_(1)
+        pr.reverse_step(lgr, xr, 250, qt, qb, e, K_PROT)
+
+    med_r, n_r = _median_time(rev_step, budget_s / 2)
+    rev = {"value": BR / (med_r * (T_PROT - 1)), "unit": "seqs/s", "cores": cores, "kind": "port",
+           "sample": f"{n_r} reverse steps (posterior marginal + multinomial draw, frozen logits) on a {BR}-sequence "
+                     f"slice (L={SEQ_LEN}, K={K_PROT}), median {med_r * 1e3:.1f} ms per step, extrapolated to the "
+                     f"{T_PROT - 1} steps of a full run; {host}"}
+    return head, lvb, rev
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--compat", action="store_true",
-                    help="time training_losses(...).mean().backward() instead of the two-launch training_step")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
-                    help="consecutive steps captured in one HIP graph (a graph launch costs ~19 us of host time: with one "
-                         "step per graph the host, not the GPU, bounds the step rate)")
-    ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary figures (reverse sampling, K=256 image configuration); for counter passes")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------ one rank
+def worker(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` "
+                         "(it starts the ranks itself) or torchrun with --nproc-per-node equal to --gpus")
     # the process group (RCCL) is only needed for N > 1; D3PM_BENCH_FORCE_PG=1 creates it for a single rank too, to
-    # rehearse the barrier / all-reduce calls of the multi-GPU run on a one-GPU box (launch through torch.distributed.run)
+    # rehearse the barrier / all-reduce calls of the multi-GPU run on a one-GPU box
     use_pg = world > 1 or bool(os.environ.get("D3PM_BENCH_FORCE_PG"))
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows "
+                         f"{torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # (the process group is created after every HIP graph below has been captured: no communicator thread is
     # alive while a stream is capturing)
 
     import d3pm_amd
-    from d3pm_amd.protein_generation.generate import reverse_step
+    from d3pm_amd.sharding import shard_range, equal_sub_batches
     from d3pm_amd.tables import protein_tables
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
 
     torch.manual_seed(1234 + rank)
     betas = d3pm_amd.generate_betas(0.0, 0.0, T, "jsd")
-    d = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type=args.kind, num_bits=5, transition_bands=None,
-                                   model_prediction="x_start", model_output="logits", loss_type="hybrid",
-                                   hybrid_coeff=LAMBDA, device=dev)
-    assert d.tables().structured
     x0 = torch.randint(0, K, (B, L, 1, 1), device=dev)
     logits = torch.randn(B, L, 1, 1, K, device=dev, requires_grad=True)
     model_fn = lambda x, tt: logits
+    sp = stream_ptr()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
+    def process(kind):
+        d = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=5, transition_bands=None,
+                                       model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                       hybrid_coeff=LAMBDA, device=dev)
+        assert d.tables().structured
+        return d
+
+    d = process(args.kind)
 
     # Default: DiscreteDiffusion.training_step -- timestep draw + q_sample (one launch, device Philox), fused loss
     # per example and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
     # --compat: the reference-shaped calls, training_losses(...).mean().backward(), which add the caller's
     # reduction and its backward (four more short launches on [B] tensors).
-    def make_step(compat, graph):
+    def make_step(dd, compat, graph):
         if compat and not graph:
             def step():
                 t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
-                x_t = d.q_sample(x0, t)                               # Philox noise on device
-                losses = d._fused(logits, x0, x_t, t, "hybrid")      # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
+                x_t = dd.q_sample(x0, t)                              # Philox noise on device
+                losses = dd._fused(logits, x0, x_t, t, "hybrid")     # fused fwd + bwd kernel (C ABI d3pm_hybrid_loss)
                 logits.grad = None
                 losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
             return step
         if compat:
-            return d3pm_amd.graphs.GraphedTrainingLosses(d, model_fn, x0, seed=1234 + rank, params=[logits]).replay
+            return d3pm_amd.graphs.GraphedTrainingLosses(dd, model_fn, x0, seed=1234 + rank, params=[logits]).replay
         if not graph:
             def step():
                 logits.grad = None
-                d.training_step(model_fn, x_start=x0)
+                dd.training_step(model_fn, x_start=x0)
             return step
-        return d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=1234 + rank, params=[logits]).replay
+        return d3pm_amd.graphs.GraphedTrainingStep(dd, model_fn, x0, seed=1234 + rank, params=[logits]).replay
 
-    step = make_step(args.compat, not args.no_graph)
-    other = make_step(not args.compat, not args.no_graph) if not args.no_secondary else None
     # n consecutive steps per graph replay (default step shape only): K timed steps = K // n replays of the n-step
     # graph + K % n replays of the one-step graph
     spg = args.steps_per_graph if not (args.compat or args.no_graph) else 1
-    multi = (d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=4321 + rank, params=[logits], steps=spg).replay
-             if spg > 1 else None)
 
-    def run_steps(k):
-        if multi is not None:
-            for _ in range(k // spg):
-                multi()
-            k %= spg
-        for _ in range(k):
-            step()
+    def make_runner(dd, seed):
+        one = make_step(dd, args.compat, not args.no_graph)
+        multi = (d3pm_amd.graphs.GraphedTrainingStep(dd, model_fn, x0, seed=seed, params=[logits], steps=spg).replay
+                 if spg > 1 else None)
 
-    # secondary: reverse sampling of 10k BLAT-length sequences, sharded; the 499-step loop of a sub-batch is one graph
-    samplers, sub = None, 0
+        def run_steps(k):
+            if multi is not None:
+                for _ in range(k // spg):
+                    multi()
+                k %= spg
+            for _ in range(k):
+                one()
+        return run_steps, one
+
+    run_steps, step = make_runner(d, 4321 + rank)
+    other = make_step(d, not args.compat, not args.no_graph) if not args.no_secondary else None
+    d_abs = run_abs = None
+    if not args.no_secondary and rank == 0:
+        d_abs = process("absorbing" if args.kind == "uniform" else "uniform")
+        run_abs, _ = make_runner(d_abs, 987 + rank)
+
+    # secondary: reverse sampling of 10k BLAT-length sequences, sharded; every rank takes its contiguous share and
+    # cuts it into equal sub-batches of at most SUB_BATCH sequences (one HIP graph replay of the 499-step loop each)
+    samplers, sub_sizes, ptab = None, [], None
     if not args.no_secondary:
-        n_local = (10000 + world - 1) // world
-        sub = min(1024, n_local)
+        lo, hi = shard_range(N_SEQS, rank, world)
+        sub_sizes = equal_sub_batches(hi - lo, SUB_BATCH)
         tok = d3pm_amd.Tokenizer()
-        Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
+        Qb, Qt = tok.q_uniform_schedule(num_steps=T_PROT, device=dev)
         ptab = protein_tables(Qt, Qb)
-        rem = n_local % sub                        # the shard's last, partial sub-batch gets a graph of its own
-        frozen = torch.randn(sub, 263, 22, device=dev)
-        emb = torch.randn(22, 64, device=dev) * 0.5
-        tvec = torch.randn(501, 64, device=dev) * 0.1
+        frozen = torch.randn(max(sub_sizes), SEQ_LEN, K_PROT, device=dev)
+        emb = torch.randn(K_PROT, 64, device=dev) * 0.5
+        tvec = torch.randn(T_PROT + 1, 64, device=dev) * 0.1
         head = torch.randn(64, 24, device=dev) * 0.3
         tiny = lambda x, tt: (emb[x] + tvec[tt][:, None, :]) @ head
         frozen_fn = lambda x, tt: frozen[:x.shape[0]]
-        # [path only, with a tiny denoiser] x [full sub-batch, remainder]
-        samplers = [[d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, nb, 263, 500, dev, seed=77 + rank + 1000 * k)
-                     for k, nb in enumerate((sub, rem)) if nb > 0] for fn in (frozen_fn, tiny)]
+        # [path only, with a tiny denoiser] x [distinct sub-batch sizes]
+        samplers = [{nb: d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, nb, SEQ_LEN, T_PROT, dev,
+                                                                seed=77 + rank + 1000 * k)
+                     for k, nb in enumerate(sorted(set(sub_sizes))) if nb > 0} for fn in (frozen_fn, tiny)]
     torch.cuda.synchronize()
+    ranks_seen = 1
     if use_pg:
         dist.init_process_group("nccl", device_id=dev)
+        ranks_seen = dist.get_world_size()
+        assert ranks_seen == world, (ranks_seen, world)
 
-    # bring the GPU to its sustained clocks first (a step is ~20 us: a short run would otherwise be timed on a
-    # part that has just left idle); then the W warm-up steps and the K timed ones
-    ramp_until = time.perf_counter() + 0.2
-    while time.perf_counter() < ramp_until:
-        run_steps(48)
+    def timed_steps(run, k, warm):
+        """W warm-up steps, then K x reps steps between barriers; reps makes the region last >= MIN_TIMED_S."""
+        # bring the GPU to its sustained clocks first (a step is ~15 us: a short run would otherwise be timed on a
+        # part that has just left idle)
+        ramp_until = time.perf_counter() + 0.2
+        while time.perf_counter() < ramp_until:
+            run(48)
+            torch.cuda.synchronize()
+        run(warm)
         torch.cuda.synchronize()
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if use_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if use_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_pg:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-    tokens = B * L * args.steps * world
+        p0 = time.perf_counter()
+        run(k)
+        torch.cuda.synchronize()
+        probe = max(time.perf_counter() - p0, 1e-6)
+        reps = max(1, int(-(-MIN_TIMED_S // probe)))
+        if use_pg:                       # the same repeat count on every rank
+            r_ = torch.tensor([reps], dtype=torch.int64, device=dev)
+            dist.all_reduce(r_, op=dist.ReduceOp.MAX)
+            reps = int(r_.item())
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run(k)
+        torch.cuda.synchronize()
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_pg:
+            el_ = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+            el = float(el_.item())
+        return el, reps
+
+    elapsed, reps = timed_steps(run_steps, args.steps, args.warmup)
+    n_timed = args.steps * reps
+    tokens = B * L * n_timed * world
 
     single_ms = None
-    if multi is not None:           # for the record: one step per graph replay (host-launch-bound)
+    if spg > 1:                     # for the record: one step per graph replay (host-launch-bound)
         for _ in range(20):
             step()
         torch.cuda.synchronize()
@@ -226,7 +376,7 @@ def main():
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - s0) * 5.0
     other_ms = None
-    if not args.no_secondary:       # the other call shape, for the record (same graph/eager mode, 100 steps)
+    if other is not None:           # the other call shape, for the record (same graph/eager mode, 100 steps)
         for _ in range(10):
             other()
         torch.cuda.synchronize()
@@ -236,63 +386,117 @@ def main():
         torch.cuda.synchronize()
         other_ms = (time.perf_counter() - o0) * 10.0
 
-    # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the
-    # stream, HIP events at both ends; rocprofv3 --kernel-trace of this command reports the same
-    # kernel's average duration (profiles/).
-    tb = d.tables()
-    t_s = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
-    xt_s = d.q_sample(x0, t_s)
-    lg_s, dl_s = logits.detach(), torch.empty_like(logits)
-    loss_s = torch.empty(B, device=dev)
-    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
-    ws = torch.empty(max(wsb // 4, 1), device=dev)
-    sp = stream_ptr()
+    def event_ms(fn, n, warm=10):
+        """Average duration of fn's launches back to back on the launch stream, between two HIP events."""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
 
-    def fused_only():
-        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_s), K, ptr(x0), 8, ptr(xt_s), 8, ptr(t_s), 4, B, L,
-                                   LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_s), None, None, 0, ptr(ws),
-                                   wsb, sp))
+    # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
+    # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
+    def fused_kernel_ms(dd, nsets=1):
+        """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
+        launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
+        tb = dd.tables()
+        t_s = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+        sets = []
+        for i in range(nsets):
+            x0_i = x0 if i == 0 else torch.randint(0, K, (B, L, 1, 1), device=dev)
+            lg_i = logits.detach() if i == 0 else torch.randn(B, L, 1, 1, K, device=dev)
+            sets.append((x0_i, dd.q_sample(x0_i, t_s), lg_i, torch.empty_like(lg_i)))
+        loss_s = torch.empty(B, device=dev)
+        wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+        ws = torch.empty(max(wsb // 4, 1), device=dev)
+        state = {"i": 0}
 
-    for _ in range(10):
-        fused_only()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(args.steps):
-        fused_only()
-    e1.record()
-    torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / args.steps
+        def fused_only():
+            x0_i, xt_i, lg_i, dl_i = sets[state["i"] % nsets]
+            state["i"] += 1
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
+                                       LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
+                                       None, 0, ptr(ws), wsb, sp))
+        return event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10)
 
-    done = done_e2e = 0
-    rev_el = e2e_el = 1.0
-    if not args.no_secondary:
+    kern_ms = fused_kernel_ms(d)
+    kern_rot_ms = None if args.no_secondary else fused_kernel_ms(d, nsets=10)
+
+    absorbing = None
+    if run_abs is not None:
+        for _ in range(3):
+            run_abs(48)
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        run_abs(400)
+        torch.cuda.synchronize()
+        a_ms = (time.perf_counter() - a0) / 400 * 1e3
+        ak = fused_kernel_ms(d_abs)
+        a_ach = BYTES_PER_TOKEN * B * L / (ak * 1e-3) / 1e9
+        absorbing = {"workload": f"the same step with {d_abs.transition_mat_type} Q (this rank only)",
+                     "ms_per_step": a_ms, "tokens_per_s": B * L / (a_ms * 1e-3),
+                     "roofline": {"bound": "hbm", "achieved": a_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": a_ach / HBM_PEAK_GBS, "kernel_ms": ak}}
+
+    # ---- secondary: reverse sampling
+    reverse = None
+    if samplers is not None:
         def run_sampler(smps):
             """This rank's share of the 10 000 sequences through the 499-step loop, one HIP graph replay per
-            sub-batch (the last one partial)."""
-            for smp in smps:
+            sub-batch."""
+            for smp in smps.values():
                 smp.sample()
             torch.cuda.synchronize()
             if use_pg:
                 dist.barrier()
             r0 = time.perf_counter()
             n = 0
-            for _ in range(n_local // sub):
-                smps[0].sample()
-                n += sub
-            if rem:
-                smps[1].sample()
-                n += rem
+            for nb in sub_sizes:
+                if nb > 0:
+                    smps[nb].sample()
+                    n += nb
             torch.cuda.synchronize()
             el = time.perf_counter() - r0
             if use_pg:
-                tt_ = torch.tensor([el], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-                el = float(tt_.item())
+                tt_ = torch.tensor([el, float(n)], dtype=torch.float64, device=dev)
+                mx = tt_.clone()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tt_, op=dist.ReduceOp.SUM)
+                return int(round(float(tt_[1].item()))), float(mx[0].item())
             return n, el
 
         done, rev_el = run_sampler(samplers[0])
         done_e2e, e2e_el = run_sampler(samplers[1])
+        # the reverse-step kernel alone, at the largest sub-batch of this rank
+        nb = max(sub_sizes)
+        xr = torch.randint(0, K_PROT, (nb, SEQ_LEN), device=dev)
+        tr = torch.full((nb,), 250, dtype=torch.long, device=dev)
+        outr = torch.empty_like(xr)
+        frz = torch.randn(nb, SEQ_LEN, K_PROT, device=dev)
+
+        def rev_only():
+            check(lib.d3pm_lvb_reverse_step(ptab.desc(), ptr(frz), K_PROT, ptr(xr), ptr(tr), nb, SEQ_LEN, None, 7, 0,
+                                            None, 1.0, 0, ptr(outr), sp))
+        rk_ms = event_ms(rev_only, 200)
+        rbytes = 4 * K_PROT + 16
+        r_ach = rbytes * nb * SEQ_LEN / (rk_ms * 1e-3) / 1e9
+        reverse = {"value": done / rev_el, "unit": "seqs/s",
+                   "what": f"full T={T_PROT} ({T_PROT - 1} steps) reverse sampling, L={SEQ_LEN}, K={K_PROT}, {N_SEQS} "
+                           f"sequences sharded over {world} GPU(s), every rank its contiguous share in sub-batches of "
+                           f"{sorted(set(sub_sizes), reverse=True)} sequences, the loop of each sub-batch replayed as "
+                           "one HIP graph, path only (frozen logits)",
+                   "sequences": done, "seconds": rev_el,
+                   "end_to_end_tiny_denoiser": done_e2e / e2e_el,
+                   "roofline": {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_device_noise via "
+                                "d3pm_lvb_reverse_step, back-to-back launches between two HIP events",
+                                "kernel_ms": rk_ms, "algorithmic_bytes_per_token": rbytes,
+                                "tokens_per_launch": nb * SEQ_LEN,
+                                "traffic": measured_traffic("k_lvb_reverse_device_noise")}}
 
     # ---- secondary: the image configuration (B=128, 32x32x1, K=256, T=1000, Gaussian Q): dense contraction on
     # the matrix cores, fused loss fwd+bwd; priced against the dense float32 MFMA peak
@@ -317,15 +521,7 @@ def main():
             check(lib.d3pm_hybrid_loss(tbi.desc(), ptr(lgi), KI, ptr(x0i), 8, ptr(xti), 8, ptr(ti), 4, BI, LI,
                                        LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dli), None, None, 0, ptr(wsi),
                                        wsbi, sp))
-        for _ in range(20):
-            dense_only()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(100):
-            dense_only()
-        e1.record()
-        torch.cuda.synchronize()
-        dms = e0.elapsed_time(e1) / 100
+        dms = event_ms(dense_only, 100, warm=20)
         tfl = 4.0 * KI * KI * BI * LI / (dms * 1e-3) / 1e12
         dense = {"workload": "image D3PM B=128 32x32x1 K=256 T=1000 Gaussian Q, fused loss fwd+bwd to dlogits",
                  "kernel_ms": dms, "tokens_per_s": BI * LI / (dms * 1e-3),
@@ -333,8 +529,8 @@ def main():
                               "flops_per_token": 4 * KI * KI, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
         del di, tbi, lgi, dli
 
-    # ---- secondary: the protein-style training loss (D3PMLVBLoss forward + gradient, float64 arithmetic) and the
-    # batched forward corruption of the collaters, B=256 L=512 K=22 n_tokens=24, through the C ABI
+    # ---- secondary: the protein-style training loss (D3PMLVBLoss forward + gradient) and the batched forward
+    # corruption of the collaters, B=256 L=512 K=22 n_tokens=24, through the C ABI
     lvb = None
     if rank == 0 and not args.no_secondary:
         BP, LP, KP, LDP = 256, 512, 22, 24
@@ -347,56 +543,111 @@ def main():
         wsbp = lib.d3pm_lvb_loss_workspace(BP, LP, KP)
         wsp = torch.empty(max(wsbp // 8, 1), dtype=torch.float64, device=dev)
 
-        def lvb_step():
+        def lvb_corrupt():
             check(lib.d3pm_corrupt(ptab.desc(), ptr(x0p), ptr(tp), BP, LP, None, 1, 0, ptr(xtp), None, sp))
+
+        def lvb_loss():
             check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
                                     1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
-        for _ in range(20):
-            lvb_step()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(100):
-            lvb_step()
-        e1.record()
-        torch.cuda.synchronize()
-        lms = e0.elapsed_time(e1) / 100
+
+        def lvb_step():
+            lvb_corrupt()
+            lvb_loss()
+        lms = event_ms(lvb_step, 200, warm=20)
+        lk_ms = event_ms(lvb_loss, 200)
+        lbytes = 8 * LDP + 16
+        l_ach = lbytes * BP * LP / (lk_ms * 1e-3) / 1e9
         lvb = {"workload": "protein-style step: batched forward corruption (device noise) + D3PMLVBLoss forward and "
-                           "gradient, B=256 L=512 K=22 n_tokens=24, float64 arithmetic, back-to-back launches",
-               "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3)}
+                           "gradient, B=256 L=512 K=22 n_tokens=24, back-to-back launches",
+               "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3),
+               "roofline": {"bound": "hbm", "achieved": l_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss via d3pm_lvb_loss, back-to-back launches "
+                            "between two HIP events", "kernel_ms": lk_ms, "algorithmic_bytes_per_token": lbytes,
+                            "traffic": measured_traffic("k_lvb_loss")}}
 
     if rank == 0:
         achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
+        traffic = measured_traffic("k_hybrid_loss", "true>(")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": (traffic["source"] + " (a committed rocprofv3 --pmc pass of this command, not "
+                                   "measured by this run)") if traffic else None,
+                "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",
+                "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
+                "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
+                        "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "
+                        "i.e. served from HBM"}
+        if kern_rot_ms:
+            roof["kernel_ms_rotating_buffers"] = kern_rot_ms
+            roof["frac_rotating_buffers"] = BYTES_PER_TOKEN * B * L / (kern_rot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
-            "metric": METRIC, "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "metric": METRIC, "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / n_timed * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic protein D3PM B={B} L={L} K={K} T={T} {args.kind} Q, per GPU: timestep draw + "
                                    "q_sample (Philox) + fused posterior/hybrid-loss fwd+bwd to per-example losses and dlogits (of the batch mean), "
                                    "denoiser excluded",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective",
                        "launch": "eager" if args.no_graph else f"hip-graph replay, {spg} step(s) per graph",
+                       "timed_steps": n_timed, "timed_repeats_of_steps": reps, "timed_seconds": elapsed,
                        "one_step_per_graph_ms_per_step": single_ms,
                        "calls": "training_losses(...).mean().backward()" if args.compat else "training_step(...)",
                        "other_call_shape_ms_per_step": other_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN},
-            "reverse_sample": None if args.no_secondary else {"value": done * world / rev_el, "unit": "seqs/s",
-                               "what": "full T=500 (499 steps) reverse sampling, L=263, K=22, 10000 sequences sharded "
-                                       f"over {world} GPU(s) in sub-batches of {sub}, the loop of each sub-batch replayed as one HIP "
-                                       "graph, path only (frozen logits)",
-                               "end_to_end_tiny_denoiser": done_e2e * world / e2e_el},
+            "roofline": roof,
+            "absorbing": absorbing,
+            "reverse_sample": reverse,
             "image_k256": dense,
             "protein_lvb": lvb,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            head, lvb_cpu, rev_cpu = cpu_baselines()
+            out["cpu_baseline"] = head
+            if lvb is not None:
+                lvb["cpu_baseline"] = lvb_cpu
+            if reverse is not None:
+                reverse["cpu_baseline"] = rev_cpu
         print(json.dumps(out), flush=True)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--compat", action="store_true",
+                    help="time training_losses(...).mean().backward() instead of the two-launch training_step")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="consecutive steps captured in one HIP graph (a graph launch costs ~19 us of host time: with one "
+                         "step per graph the host, not the GPU, bounds the step rate)")
+    ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (reverse sampling, K=256 image configuration, protein-style loss, "
+                         "the other transition kind); for counter passes")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if os.environ.get("D3PM_BENCH_SPAWN_ECHO"):
+        # launch rehearsal without a GPU: every rank reports the environment it was started with
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            return launch_ranks(args.gpus, argv)
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        path = os.environ["D3PM_BENCH_SPAWN_ECHO"]
+        with open(f"{path}.{rec['RANK']}", "w") as f:
+            json.dump(rec, f)
+        if rec["RANK"] == "0":
+            print(json.dumps({"n_gpus": int(rec["WORLD_SIZE"]), "echo": True}), flush=True)
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)          # before any GPU call: the parent never touches the device
+    worker(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

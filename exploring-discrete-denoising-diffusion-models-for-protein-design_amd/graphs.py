@@ -32,7 +32,9 @@ class GraphedTrainingLosses:
         dev = x_start.device
         # parameters usually predate the capture stream; the mismatch torch warns about is intended here
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        diffusion.tables()                                   # builds digests now: set-up syncs are not capturable
+        # builds the digests now (set-up syncs are not capturable) and keeps them: the captured launches hold raw
+        # pointers into these buffers, which a later change of q_mats / force_dense would otherwise free
+        self._tables = diffusion.tables()
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -85,7 +87,7 @@ class GraphedTrainingStep:
         self.seed, self.steps = int(seed), steps
         dev = self.x_start.device
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        diffusion.tables()
+        self._tables = diffusion.tables()                    # pinned: the graph holds raw pointers into the digests
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -174,7 +176,7 @@ class GraphedBpdSweep:
         self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
         self.seed = int(seed)
         dev = x_start.device
-        diffusion.tables()                                   # set-up syncs are not capturable
+        self._tables = diffusion.tables()                    # set-up syncs are not capturable; pinned for the graph
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.stride = 4 * diffusion.num_timesteps
         side = torch.cuda.Stream(device=dev)
@@ -206,7 +208,7 @@ class GraphedPSampleLoop:
     def __init__(self, diffusion, model_fn, shape, seed: int = 0, num_timesteps=None):
         self.diffusion, self.model_fn, self.shape = diffusion, model_fn, tuple(shape)
         dev = torch.device(diffusion.device)
-        diffusion.tables()                                   # set-up syncs are not capturable
+        self._tables = diffusion.tables()                    # set-up syncs are not capturable; pinned for the graph
         self.steps = diffusion.num_timesteps if num_timesteps is None else num_timesteps
         self.x = torch.zeros(self.shape, dtype=torch.int64, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)

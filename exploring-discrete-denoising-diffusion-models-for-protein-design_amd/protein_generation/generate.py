@@ -10,6 +10,7 @@ import torch
 from .. import _lib
 from .._lib import lib, check, ptr, stream_ptr
 from ..tables import protein_tables
+from ..sharding import shard_range, equal_sub_batches, gather_token_shards  # noqa: F401  (re-exported)
 
 
 def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, exclude_last_prefix=0, rng=None):
@@ -81,36 +82,11 @@ def sample_and_save(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, s
     return strings
 
 
-def shard_range(n_total: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of n_total items for `rank`; sizes differ by at most one."""
-    per, rem = divmod(n_total, world)
-    lo = rank * per + min(rank, rem)
-    return lo, lo + per + (1 if rank < rem else 0)
-
-
-def gather_token_shards(local: torch.Tensor, group=None):
-    """All ranks' [n_r, L] token shards, concatenated in rank order, on every rank
-    (uint8 on the wire: K <= 256).  Ragged shards are padded to the largest.  Without
-    an initialised process group the local shard is returned."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
-    world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
-    sizes = [int(x.item()) for x in sizes]
-    padded = torch.zeros((max(sizes), local.shape[1]), dtype=torch.uint8, device=local.device)
-    padded[:local.shape[0]] = local.to(torch.uint8)
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[:n] for p, n in zip(parts, sizes)]).to(local.dtype)
-
-
 def sample_and_save_sharded(out_path, num_seqs, model, tokenizer, Q, Q_bar, timesteps, seq_len, device, batch_size=1024,
                             seed=0, graph=True):
     """``sample_and_save`` (generate.py:118-130) over all ranks of the default
     process group: every rank generates its contiguous share of the `num_seqs`
-    sequences in sub-batches of `batch_size` from its own Philox stream
+    sequences in equal sub-batches of at most `batch_size` from its own Philox stream
     (seed + rank), with no communication until the final gather; rank 0 writes the
     FASTA file in the reference's format.  ``graph``: replay the T-1 step loop of a
     sub-batch as one HIP graph (``model`` must be capturable).  Returns the strings
@@ -124,7 +100,9 @@ def sample_and_save_sharded(out_path, num_seqs, model, tokenizer, Q, Q_bar, time
     tables = protein_tables(Q, Q_bar, device=device)
     model.eval()
     out = torch.empty((hi - lo, seq_len), dtype=torch.long, device=device)
-    sub = max(1, min(batch_size, hi - lo))
+    # equal sub-batches (sizes differ by at most one; one graph of the larger size serves both, a surplus row is
+    # dropped): a short last sub-batch would run at the launch floor of its kernels
+    sub = max(equal_sub_batches(hi - lo, batch_size), default=1)
     done = 0
     if graph and hi > lo:
         smp = GraphedReverseSampler(tables, model, sub, seq_len, timesteps, device, seed=seed + rank)

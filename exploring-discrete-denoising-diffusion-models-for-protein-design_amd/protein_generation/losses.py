@@ -87,8 +87,10 @@ def _lvb_forward(self, src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q,
     assert predictions.shape[:-1] == x0.shape and predictions.shape[-1] >= K
     qd = None
     if q is not None:
-        qd = q.to(device=dev, dtype=torch.float64).contiguous()
-        assert qd.shape == x0.shape + (K,), qd.shape
+        # the reference only reads q[i] for i < B (losses.py:56-60, :128-132), so a leading size beyond B is
+        # accepted: CollaterMSA returns q_x appended twice, [2B, D, L, K] (dataset.py:287,291)
+        assert q.shape[1:] == x0.shape[1:] + (K,) and q.shape[0] >= x0.shape[0], (q.shape, x0.shape)
+        qd = q[:x0.shape[0]].to(device=dev, dtype=torch.float64).contiguous()
     tables = protein_tables(Q, Q_bar, device=dev)
     B = x0.shape[0]
     baked = 1.0 if self.evaluation else float(np.float32(1.0) / np.float32(max(B, 1)))
