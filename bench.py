@@ -322,7 +322,18 @@ def worker(args):
     torch.cuda.synchronize()
     ranks_seen = 1
     if use_pg:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on file descriptor 1 when its first communicator comes up: send it to
+        # stderr, so that stdout carries the JSON line only
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
         ranks_seen = dist.get_world_size()
         assert ranks_seen == world, (ranks_seen, world)
 
