@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import contextlib
+import faulthandler
 import json
 import os
 import sys
@@ -60,7 +61,7 @@ class ByteNetLike(nn.Module):
         return self.head(self.norm(h)).reshape(*shape, -1).float()
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
@@ -69,26 +70,65 @@ def main():
     ap.add_argument("--bits", type=int, default=5, help="K = 2**bits classes")
     ap.add_argument("--d-model", type=int, default=256)
     ap.add_argument("--layers", type=int, default=8)
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI, one rank per GPU)")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (= RCCL over xGMI, one rank per GPU) or gloo (rehearsal of the N > 1 code path on a box "
+                         "with fewer GPUs than ranks: gradients are staged through the host)")
     ap.add_argument("--bf16", action="store_true", help="autocast the denoiser to bfloat16 (the path stays float32)")
-    args = ap.parse_args()
+    ap.add_argument("--watchdog", type=float, default=120.0,
+                    help="seconds without reaching the next phase after which every thread's stack is dumped and the "
+                         "process exits (0 = off)")
+    args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def phase(name):
+        """One line per phase on stderr and a fresh watchdog: a stalled collective names itself."""
+        print(f"[train_ddp rank {rank}] {name}", file=sys.stderr, flush=True)
+        if args.watchdog > 0:
+            faulthandler.dump_traceback_later(args.watchdog, exit=True)
+
+    phase("start")
     ngpu = torch.cuda.device_count()
-    dev = torch.device("cuda", local % max(ngpu, 1))
+    if ngpu == 0:
+        raise SystemExit("train_ddp.py needs a GPU: the D3PM kernels have no CPU path")
+    if world > 1 and args.backend == "nccl" and world > ngpu:
+        raise SystemExit(f"--backend nccl needs one GPU per rank ({world} ranks, {ngpu} GPU(s)): RCCL does not form a "
+                         "communicator with two ranks on one device; use --backend gloo to rehearse the code path")
+    dev = torch.device("cuda", local % ngpu)
     torch.cuda.set_device(dev)
+    gloo = args.backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        phase(f"init_process_group({args.backend})")
+        dist.init_process_group(args.backend, **({} if gloo else {"device_id": dev}))
+    # timing / logging collectives: host tensors under gloo (no device staging inside the collective), device
+    # tensors under RCCL
+    cdev = torch.device("cpu") if gloo else dev
 
     import d3pm_amd
     K, T, B, L = 2 ** args.bits, 500, args.batch_per_gpu, args.seq_len
     torch.manual_seed(1234)                                   # same initial weights on every rank
     model = ByteNetLike(K, T, args.d_model, args.layers).to(dev)
-    net = nn.parallel.DistributedDataParallel(model, device_ids=None if args.backend == "gloo" else [dev.index]) \
-        if world > 1 else model
+    torch.cuda.synchronize()
+    # RCCL: stock DistributedDataParallel (bucketed all-reduce overlapped with backward; identical seeds give
+    # identical weights, so the constructor's parameter broadcast is skipped).  gloo: the reducer's all-reduce of
+    # DEVICE buckets from inside backward never completes on this ROCm build (both ranks stall in
+    # _engine_run_backward), so the rehearsal averages the gradients through host tensors after backward instead.
+    use_ddp = world > 1 and not gloo
+    phase("wrap denoiser in DistributedDataParallel" if use_ddp else "denoiser built")
+    net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], init_sync=False) if use_ddp else model
+
+    def average_grads_via_host():
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        flat = torch.cat([g_.reshape(-1) for g_ in grads]).cpu()
+        dist.all_reduce(flat)
+        flat = (flat / world).to(dev)
+        off = 0
+        for g_ in grads:
+            g_.copy_(flat[off:off + g_.numel()].view_as(g_))
+            off += g_.numel()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform",
                                    num_bits=args.bits, transition_bands=None, model_prediction="x_start",
@@ -97,7 +137,6 @@ def main():
     data = torch.randint(0, K, (B, L, 1, 1), device=dev)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    path_ms = []
 
     def model_fn(x, t):
         ev[1].record()                                        # corruption done
@@ -109,9 +148,11 @@ def main():
     def step(sync=True):
         opt.zero_grad(set_to_none=True)
         ev[0].record()
-        ctx = net.no_sync() if (world > 1 and not sync) else contextlib.nullcontext()
+        ctx = net.no_sync() if (use_ddp and not sync) else contextlib.nullcontext()
         with ctx:
             out = d.training_step(model_fn, x_start=data)     # backward through the denoiser included
+        if world > 1 and gloo and sync:
+            average_grads_via_host()
         opt.step()
         return out
 
@@ -125,19 +166,28 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            tt = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el / n * 1e3, out
 
+    phase(f"{args.warmup} warm-up steps")
+    first = None
     for _ in range(args.warmup):
-        step()
+        o = step()
+        if first is None:
+            first = float(o["losses"].double().mean().item())
+    phase(f"{args.steps} timed steps")
     ms, out = timed(args.steps)
+    # weights stay identical across ranks only if every rank applied the same averaged gradient (checked here,
+    # before the steps without all-reduce let the ranks drift apart on purpose)
+    wsum = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().to(cdev)
     # share of the path: corruption (ev0 -> ev1) measured inside a step; the fused loss + mean by direct timing
     torch.cuda.synchronize()
     corrupt_ms = ev[0].elapsed_time(ev[1])
+    phase("path share")
     with torch.no_grad():
-        logits = net(out["x_t"], out["t"]).detach()
+        logits = model(out["x_t"], out["t"]).detach()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     frozen = lambda x, t: logits
     d.training_step(frozen, x_start=data, backward=False)
@@ -146,25 +196,40 @@ def main():
         d._fused(logits.requires_grad_(True), data, out["x_t"], out["t"], "hybrid")
     e1.record(); torch.cuda.synchronize()
     loss_ms = e0.elapsed_time(e1) / 20
-    nosync_ms = timed(args.steps, sync=False)[0] if world > 1 else ms
-    losses = out["losses"].double().mean()
     if world > 1:
+        phase(f"{args.steps} timed steps without gradient all-reduce")
+    nosync_ms = timed(args.steps, sync=False)[0] if world > 1 else ms
+    losses = out["losses"].double().mean().to(cdev)
+    spread = torch.zeros((), dtype=torch.float64, device=cdev)
+    if world > 1:
+        phase("final reductions")
         dist.all_reduce(losses)
         losses /= world
+        lo, hi = wsum.clone(), wsum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = (hi - lo).abs() / hi.abs().clamp_min(1e-30)
+    result = {
+        "what": "DDP training step: ByteNet-like denoiser (stock PyTorch) + D3PM training_step (this package)",
+        "n_gpus": world, "backend": args.backend if world > 1 else None, "global_batch": B * world, "seq_len": L,
+        "K": K, "denoiser": {"d_model": args.d_model, "layers": args.layers, "bf16": args.bf16,
+                             "params": sum(p.numel() for p in model.parameters())},
+        "ms_per_step": ms, "tokens_per_s": B * L * world / (ms * 1e-3),
+        "path_ms": {"corrupt_and_timestep_draw": corrupt_ms, "fused_loss_fwd_bwd": loss_ms},
+        "path_share": (corrupt_ms + loss_ms) / ms,
+        "allreduce_share": max(0.0, (ms - nosync_ms) / ms) if world > 1 else 0.0,
+        "first_step_loss_bits_per_dim": first,
+        "mean_loss_bits_per_dim": float(losses.item()),
+        "weight_checksum_spread_over_ranks": float(spread.item())}
     if rank == 0:
-        print(json.dumps({
-            "what": "DDP training step: ByteNet-like denoiser (stock PyTorch) + D3PM training_step (this package)",
-            "n_gpus": world, "backend": args.backend if world > 1 else None, "global_batch": B * world, "seq_len": L,
-            "K": K, "denoiser": {"d_model": args.d_model, "layers": args.layers, "bf16": args.bf16,
-                                 "params": sum(p.numel() for p in model.parameters())},
-            "ms_per_step": ms, "tokens_per_s": B * L * world / (ms * 1e-3),
-            "path_ms": {"corrupt_and_timestep_draw": corrupt_ms, "fused_loss_fwd_bwd": loss_ms},
-            "path_share": (corrupt_ms + loss_ms) / ms,
-            "allreduce_share": max(0.0, (ms - nosync_ms) / ms) if world > 1 else 0.0,
-            "mean_loss_bits_per_dim": float(losses.item())}), flush=True)
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    phase_done = f"[train_ddp rank {rank}] done"
+    print(phase_done, file=sys.stderr, flush=True)
+    return result
 
 
 if __name__ == "__main__":
