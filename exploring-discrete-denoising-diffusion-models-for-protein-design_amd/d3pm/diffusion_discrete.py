@@ -488,8 +488,11 @@ class DiscreteDiffusion:
         """First half of ``training_step``: one launch drawing the timesteps and the
         noisy tokens.  ``rng=(seed, counter)``: Philox stream offset = ``offset`` + the
         counter's value when the kernel runs.  It depends on nothing but ``x_start`` and
-        the counter, so the next step's corruption can run (on another stream) while
-        this step's denoiser and loss do.  Returns the dict ``loss_step`` takes."""
+        the counter.  Issue both halves on ONE stream: the counter is advanced by the
+        loss kernel, and a HIP graph with the corruption on a second captured stream
+        (fork / join inside the capture) left a hardware queue hung under the profiler on
+        the test machine, so no multi-stream use of the two halves is supported.
+        Returns the dict ``loss_step`` takes."""
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         if self.model_prediction != "x_start":
