@@ -12,6 +12,8 @@
 #include "layout.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace d3pm {
@@ -964,6 +966,53 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
   } else {
     rc = structured_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
                                 hybrid_coeff, grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------ the entry point that allocates nothing
+// Partial sums of d3pm_hybrid_loss_static: one (vb, ce) pair per workgroup, written in full by the loss kernel
+// and read by k_loss_finalize in the same call, so nothing in it has to start at zero.  Every GPU the library runs
+// on holds its own copy of the array for the life of the process.
+constexpr size_t STATIC_SCRATCH_BYTES = 128 * 1024;
+static __device__ __align__(256) float g_loss_scratch[STATIC_SCRATCH_BYTES / sizeof(float)];
+
+// Device address of g_loss_scratch on the current device (the array's name is a host-side stand-in, not a device
+// address: kernels get this pointer).  Looked up once per device, with that device current.
+static int static_scratch(float** out) {
+  constexpr int MAX_DEVICES = 64;
+  static std::mutex mu;
+  static float* ptrs[MAX_DEVICES] = {};
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  D3PM_CHECK_ARG(dev >= 0 && dev < MAX_DEVICES, "device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_loss_scratch));
+    if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(g_loss_scratch)");
+    D3PM_CHECK_ARG(p, "hipGetSymbolAddress returned a null address");
+    ptrs[dev] = p;
+  }
+  *out = ptrs[dev];
+  return D3PM_OK;
+}
+
+extern "C" int d3pm_hybrid_loss_static(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0,
+                                       int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes, int B,
+                                       long npos, int loss_type, float hybrid_coeff, float grad_scale,
+                                       const float* grad_out, float* vb, float* ce, float* loss, float* dlogits,
+                                       float* loss_mean, uint64_t* rng_counter, uint64_t rng_step, void* stream) {
+  float* scratch = nullptr;
+  if (int rc = static_scratch(&scratch)) return rc;
+  const int rc = d3pm_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
+                                  hybrid_coeff, grad_scale, grad_out, vb, ce, loss, dlogits, loss_mean, rng_counter,
+                                  rng_step, scratch, STATIC_SCRATCH_BYTES, stream);
+  if (rc == D3PM_EINVAL && strstr(d3pm_last_error(), "workspace too small")) {
+    set_error("d3pm_hybrid_loss_static: B = %d x npos = %ld needs more partial sums than the %zu-byte static scratch "
+              "holds (8 bytes per workgroup); call d3pm_hybrid_loss with a workspace of "
+              "d3pm_hybrid_loss_workspace() bytes instead", B, npos, STATIC_SCRATCH_BYTES);
   }
   return rc;
 }

@@ -180,6 +180,25 @@ int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld,
                      float* loss_mean, uint64_t* rng_counter, uint64_t rng_step,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* d3pm_hybrid_loss for callers that cannot allocate device memory or carry a
+ * workspace (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments, results
+ * and kernels as d3pm_hybrid_loss, minus the workspace: the per-workgroup
+ * partial sums go to a 128 KiB array in the library's device image (one copy
+ * per GPU, held until the process ends).  The call allocates and frees nothing.
+ * Limit: 8 bytes per workgroup of the loss launch, i.e. at most 16 384
+ * workgroups -- any structured (uniform / absorbing) problem, and dense
+ * (Gaussian / banded) problems up to B x chunks <= 16 384; beyond that the call
+ * returns D3PM_EINVAL and launches nothing.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (two streams, two threads) race on it;
+ * calls in stream order do not.  The first call on a device looks the array's
+ * address up (hipGetSymbolAddress): make that call outside a graph capture. */
+int d3pm_hybrid_loss_static(const d3pm_tables_f32* tb, const float* logits, long ld,
+                            const void* x0, int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
+                            int B, long npos, int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out,
+                            float* vb, float* ce, float* loss, float* dlogits,
+                            float* loss_mean, uint64_t* rng_counter, uint64_t rng_step, void* stream);
+
 /* In-place per-sample rescale g[b,:] *= upstream[b]/baked; blocks whose
  * upstream[b] equals `baked` exactly touch nothing.  Backward of the autograd
  * node when the upstream gradient differs from the scale d3pm_hybrid_loss /

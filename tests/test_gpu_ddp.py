@@ -24,14 +24,14 @@ def _load_tool():
 
 
 def test_training_harness_single_rank():
-    """Three optimiser steps of a 2-layer denoiser with the two-launch training step: finite losses that fall,
-    the path a small share of the step."""
+    """Three optimiser steps of a 2-layer denoiser with the two-launch training step: finite losses (their size
+    depends on the timesteps drawn, so no trend is asserted over so few steps), the path a small share of the step."""
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)
     res = _load_tool().main(["--steps", "3", "--warmup", "2", "--layers", "2", "--d-model", "128",
                              "--batch-per-gpu", "64", "--watchdog", "100"])
     assert res["n_gpus"] == 1 and res["global_batch"] == 64
-    assert 0.0 < res["mean_loss_bits_per_dim"] < res["first_step_loss_bits_per_dim"] < 10.0
+    assert 0.0 < res["mean_loss_bits_per_dim"] < 10.0 and 0.0 < res["first_step_loss_bits_per_dim"] < 10.0
     assert 0.0 < res["path_share"] < 0.5 and res["allreduce_share"] == 0.0
 
 
