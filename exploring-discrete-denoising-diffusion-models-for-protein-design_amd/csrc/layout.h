@@ -88,6 +88,27 @@ __device__ __forceinline__ void store_slots_off(char* __restrict__ base, unsigne
   }
 }
 
+// The same with the non-temporal cache policy: a streamed output that no workgroup of the launch reads again
+// (dirty lines left in the XCDs' L2 are written back only when the kernel ends; streamed out, that traffic
+// overlaps the kernel's own run time).
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+template <class L>
+__device__ __forceinline__ void store_slots_off_nt(char* __restrict__ base, unsigned row_off, int g, int K,
+                                                   const float (&z)[L::V]) {
+  if constexpr (L::VEC) {
+#pragma unroll
+    for (int h = 0; h < L::V / 4; ++h)
+      __builtin_nontemporal_store(v4f_nt{z[4 * h + 0], z[4 * h + 1], z[4 * h + 2], z[4 * h + 3]},
+                                  reinterpret_cast<v4f_nt*>(base + (row_off + 4u * (unsigned)L::piece(g, h))));
+  } else {
+#pragma unroll
+    for (int v = 0; v < L::V; ++v) {
+      const int c = L::cls(g, v);
+      if (c < K) __builtin_nontemporal_store(z[v], reinterpret_cast<float*>(base + (row_off + 4u * (unsigned)c)));
+    }
+  }
+}
+
 template <class L>
 __device__ __forceinline__ void store_slots(float* __restrict__ row, int g, int K, const float (&z)[L::V]) {
   if constexpr (L::VEC) {
