@@ -619,238 +619,228 @@ extern "C" int d3pm_debug_timeline(void* host_out) {
 }
 #endif
 
-// ------------------------------------------------------------------ fused hybrid loss, two-phase form
-// The same arithmetic as k_hybrid_loss, ordered so that nothing waits for the timestep chain with empty hands.
-// A lane group takes NT tokens per round.  Phase A needs only the rows: all NT rows (and the tokens) are requested
-// at kernel entry, ahead of the timestep -> digest -> LDS chain, and their softmax (max, exp2, sum, normalise) is
-// taken as they arrive, i.e. while that chain is in flight.  Phase B, after the digests have landed, does the
-// posterior / KL / gradient part from the normalised probabilities and streams the gradient rows out with
-// non-temporal stores.  Vector loads retire in issue order, so the order of issue is: tokens, rows, the special
-// classes' logits (an L1 hit on the row), digests; phase A(u) then waits for row u only.
-template <class L, bool GRAD, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_hybrid_loss2(
-    ImgArgs a, const float* __restrict__ logits, long ld, int loss_type, float hybrid_coeff, float grad_scale,
+// ------------------------------------------------------------------ fused hybrid loss, one token per lane
+// For K <= 32 (rows of at most 128 bytes) a lane takes a whole token: its K classes sit in registers, so there is
+// no cross-lane reduction, no per-token scalar work repeated on several lanes, and every per-class constant of the
+// timestep is wave-uniform (scalar registers).  Rows are moved between global memory and that layout through a
+// wave-private LDS image: coalesced 16-byte pieces in, one padded row per lane out (row stride = row + 16 bytes,
+// which spreads a 16-lane read group over all banks), and the same image in reverse for the gradient rows.
+// Arithmetic as in k_hybrid_loss with three simplifications that hold for every row-stochastic column-structured
+// table: diag_j - off_j is one value for all classes (every row sums to one), hence sum_j f2_j needs no reduction
+// (sum_j pi_j = 1), and the term R = sum_j gf2_j off_j, which enters g pi_j and <pi, g pi> alike, drops out of the
+// softmax backward.  The softmax stays unnormalised (e_j = 2^(z_j - m)); 1 / sum e is folded into the per-token
+// scalars.  The two special classes (x0, x_t) are read from and patched into the lane's own LDS row.
+template <int KC> struct TplCfg {
+  static constexpr int RB = 4 * KC, PIECES = RB / 16, STRIDE = RB + 16;
+  static_assert(KC % 4 == 0 && KC <= 32 && (PIECES % 2) == 0, "row of 2, 4, 6 or 8 16-byte pieces");
+};
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave complete in order; this only stops the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KC, bool GRAD, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
+    ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
     const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
-  constexpr int NT = 4;
+  using C = TplCfg<KC>;
+  extern __shared__ __align__(16) char tpl_rows[];          // [waves][64][STRIDE]
   __shared__ float red[2 * MAX_WAVES];
-  __shared__ float s_ad[256], s_ao[256], s_bdo[256], s_boe[256];
-  const int K = a.tb.K;
+  // column x_t of Q_t (+eps) and off + eps of Qbar_{t-1}, by class: a copy per wave, so that no wave waits for another
+  __shared__ float s_tab[MAX_WAVES][3][32];
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const unsigned tpp = blockDim.x / L::G;     // tokens per pass
-  const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * ld);
-  char* __restrict__ drow = GRAD ? (char*)(dlogits + (size_t)b * a.npos * ld) : nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
+  const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
+  const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * KC);
+  char* __restrict__ drow = GRAD ? (char*)(dlogits + (size_t)b * a.npos * KC) : nullptr;
   const char* __restrict__ x0row = (const char*)a.x0 + (size_t)b * a.npos * a.x0_bytes;
   const char* __restrict__ xtrow = (const char*)a.xt + (size_t)b * a.npos * a.xt_bytes;
   const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
-  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
-  const unsigned pbeg = (unsigned)(chunk * a.chunk_pos) + slot;
-  const unsigned row_bytes = (unsigned)ld * 4u;
-  const unsigned kmax = (unsigned)(K - 1);
+  char* const img = tpl_rows + (size_t)wave * 64 * C::STRIDE;
+  char* const myrow = img + lane * C::STRIDE;
 
   if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
 
   D3PM_TL_DECL;
   D3PM_TL(0);
-  float zz[NT][L::V];          // logits, then probabilities
-  int x0s[NT], xts[NT];
-  float sp0[NT], spt[NT];      // logits of the token's two special classes (x0, x_t)
-  auto issue_tokens = [&](int u, unsigned pos) {
-    x0s[u] = *reinterpret_cast<const int*>(x0row + (pos << x0sh));
-    xts[u] = *reinterpret_cast<const int*>(xtrow + (pos << xtsh));
-  };
-  auto issue_row = [&](int u, unsigned pos) { load_slots_off<L>(lrow, pos * row_bytes, g, K, -INFINITY, zz[u]); };
-  // tokens outside [0, K) would index LDS and the row out of bounds: they are clamped (the result for such a
-  // token is meaningless, but nothing faults)
-  auto issue_special = [&](int u, unsigned pos) {
-    x0s[u] = (int)min((unsigned)x0s[u], kmax);
-    xts[u] = (int)min((unsigned)xts[u], kmax);
-    sp0[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)x0s[u]));
-    spt[u] = *reinterpret_cast<const float*>(lrow + (pos * row_bytes + 4u * (unsigned)xts[u]));
-  };
+  // piece h of this lane in the coalesced order: row (of the wave's 64) and byte offset inside the row
+  v4f_nt stage[C::PIECES];
+  int x0 = 0, xt = 0;
+  auto issue = [&](unsigned base) {           // base: first position of this wave's 64 tokens
+    const unsigned last = p1 - 1 - base;      // rows past the end re-read the last one (never stored)
+    const unsigned mine = min((unsigned)lane, last);
+    x0 = *reinterpret_cast<const int*>(x0row + ((base + mine) << x0sh));
+    xt = *reinterpret_cast<const int*>(xtrow + ((base + mine) << xtsh));
 #pragma unroll
-  for (int u = 0; u < NT; ++u)
-    if (pbeg + u * tpp < p1) issue_tokens(u, pbeg + u * tpp);
-#pragma unroll
-  for (int u = 0; u < NT; ++u)
-    if (pbeg + u * tpp < p1) issue_row(u, pbeg + u * tpp);
+    for (int h = 0; h < C::PIECES; ++h) {
+      const unsigned q = h * 64 + lane, r = min(q / C::PIECES, last), j = q % C::PIECES;
+      stage[h] = *reinterpret_cast<const v4f_nt*>(lrow + ((base + r) * C::RB + j * 16));
+    }
+  };
+  unsigned base = pbeg + wave * 64;
+  if (base < p1) issue(base);
   int t = load_tok(a.t, b, a.t_bytes);
   t = max(0, min(t, a.tb.T - 1));
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
-#pragma unroll
-  for (int u = 0; u < NT; ++u)
-    if (pbeg + u * tpp < p1) issue_special(u, pbeg + u * tpp);
-  D3PM_TL_AFTER(2, spt[0]);
-  float bdo[L::V], boe[L::V], bo[L::V];
-  float sum_boe = 0, sum_bo = 0;
-  float f_ad = 0, f_ao = 0, f_d = 0, f_o = 0;
+  // per-class constants of the timestep, wave-uniform: off_j + eps of Qbar_{t-1} by class, their sum, diag - off
+  float boe[KC];
+  float bdo = 0, sum_boe = 0;
   if (need_post) {
-    load_digest<L>(a.tb.qbar_digest, t - 1, 0, K, g, bdo);     // diag for now
-    load_digest<L>(a.tb.qbar_digest, t - 1, 1, K, g, bo);
-    if (threadIdx.x < K) {                   // K <= blockDim.x (checked by the host)
-      f_ad = dg(a.tb.qone_digest, t, 0, K)[threadIdx.x];
-      f_ao = dg(a.tb.qone_digest, t, 1, K)[threadIdx.x];
-      f_d = dg(a.tb.qbar_digest, t - 1, 0, K)[threadIdx.x];
-      f_o = dg(a.tb.qbar_digest, t - 1, 1, K)[threadIdx.x];
+    const float vd = lane < KC ? dg(a.tb.qbar_digest, t - 1, 0, KC)[lane] : 0.0f;
+    const float vo = lane < KC ? dg(a.tb.qbar_digest, t - 1, 1, KC)[lane] : 0.0f;
+    const float vboe = vo + eps;
+    if (lane < KC) {
+      s_tab[wave][0][lane] = dg(a.tb.qone_digest, t, 0, KC)[lane] + eps;
+      s_tab[wave][1][lane] = dg(a.tb.qone_digest, t, 1, KC)[lane] + eps;
+      s_tab[wave][2][lane] = vboe;
     }
+    bdo = lane_bcast(vd - vo, 0);
+    sum_boe = wave_sum(lane < KC ? vboe : 0.0f);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) boe[j] = lane_bcast(vboe, j);
   }
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
   const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
   const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
-  const float tok = (g == 0) ? 1.0f : 0.0f;
-  constexpr int CS = L::VEC ? 1 : L::G;      // class stride between slots
-  float acc_vb = 0, acc_ce = 0;              // per-lane partial sums, in bits; lane 0 of a group carries the token
+  float acc_vb = 0, acc_ce = 0;
   bool first = true;
-  for (unsigned pos0 = pbeg;; pos0 += NT * tpp) {
-    // ---- phase A: softmax of every row of the round (needs neither the timestep nor the digests)
-    float mnegs[NT], invs[NT], l2s[NT], ms[NT];
+  for (;; base += blockDim.x) {
+    const bool work = base < p1;              // uniform over the wave
+    float e[KC];
+    float m = 0, inv = 0, l2s = 0, mneg = 0;
+    if (work) {
+      // ---- rows into the lane-per-token layout
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      if (pos0 + u * tpp >= p1) break;       // whole lane groups leave together
-      float m = zz[u][0];
+      for (int h = 0; h < C::PIECES; ++h) {
+        const unsigned q = h * 64 + lane;
+        *reinterpret_cast<v4f_nt*>(img + (q / C::PIECES) * C::STRIDE + (q % C::PIECES) * 16) = stage[h];
+      }
+      if (first) D3PM_TL(2);
+      wave_lds_fence();
 #pragma unroll
-      for (int v = 1; v < L::V; ++v) m = fmaxf(m, zz[u][v]);
-      m = group_max<L::G>(m);
-      const float mneg = -m * LOG2E;
+      for (int j = 0; j < C::PIECES; ++j) {
+        const v4f_nt q = *reinterpret_cast<const v4f_nt*>(myrow + 16 * j);
+        e[4 * j] = q.x; e[4 * j + 1] = q.y; e[4 * j + 2] = q.z; e[4 * j + 3] = q.w;
+      }
+      // ---- phase A: softmax statistics (no timestep needed)
+      m = e[0];
+#pragma unroll
+      for (int j = 1; j < KC; ++j) m = fmaxf(m, e[j]);
+      mneg = -m * LOG2E;
       float s = 0;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) { zz[u][v] = fast_exp2(fmaf(zz[u][v], LOG2E, mneg)); s += zz[u][v]; }
-      s = group_sum<L::G>(s);
-      const float inv = fast_rcp(s);
-#pragma unroll
-      for (int v = 0; v < L::V; ++v) zz[u][v] *= inv;
-      ms[u] = m; mnegs[u] = mneg; invs[u] = inv; l2s[u] = fast_log2(s);
-      if (u == 0 && first) D3PM_TL_AFTER(3, l2s[0]);
+      for (int j = 0; j < KC; ++j) { e[j] = fast_exp2(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
+      inv = fast_rcp(s);
+      l2s = fast_log2(s);
+      if (first) D3PM_TL_AFTER(3, l2s);
     }
-    if (first) D3PM_TL_AFTER(4, l2s[NT - 1]);
     if (first) {
       first = false;
-      // per-class constants of Qbar_{t-1} for this lane's slots, their sums over all classes, and the tables
-      // indexed by token values in LDS
-      if (need_post) {
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          const bool ok = L::VEC || L::cls(g, v) < K;
-          bdo[v] = ok ? bdo[v] - bo[v] : 0.0f;
-          boe[v] = ok ? bo[v] + eps : 1.0f;        // masked slots: f2 = 1
-          bo[v] = ok ? bo[v] : 0.0f;
-          sum_boe += ok ? boe[v] : 0.0f;
-          sum_bo += bo[v];
-        }
-        sum_boe = group_sum<L::G>(sum_boe);
-        sum_bo = group_sum<L::G>(sum_bo);
-        if (threadIdx.x < K) {
-          s_ad[threadIdx.x] = f_ad + eps;
-          s_ao[threadIdx.x] = f_ao + eps;
-          s_bdo[threadIdx.x] = f_d - f_o;
-          s_boe[threadIdx.x] = f_o + eps;
-        }
-        __syncthreads();
-      }
-      D3PM_TL(5);
+      wave_lds_fence();                       // this wave's table copy
+      D3PM_TL(4);
     }
-    // ---- phase B: posterior, KL, gradient
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const unsigned pos = pos0 + u * tpp;
-      if (pos >= p1) break;
-      const int x0 = x0s[u], xt = xts[u];
-      const float mneg = mnegs[u], inv = invs[u];
-      const float ce_bits = fmaf(ms[u] - sp0[u], LOG2E, l2s[u]);     // -log2 softmax(z)[x0]
-      acc_ce = fmaf(tok, ce_bits, acc_ce);
-      const int d0 = x0 - L::cls(g, 0), dt = xt - L::cls(g, 0);       // slot of x0 / x_t in this lane, if any
-      float gz[L::V];
-      if (!need_post) {
-        acc_vb = fmaf(tok, ce_bits, acc_vb);
-        if constexpr (GRAD) {
-          const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) gz[v] = fmaf(zz[u][v], w, (d0 == v * CS) ? -w : 0.0f);
-        }
-      } else {
-        const float a_d = s_ad[xt], a_o = s_ao[xt], da = a_d - a_o;
-        const float bdo_x0 = s_bdo[x0], boe_x0 = s_boe[x0], bdo_xt = s_bdo[xt], boe_xt = s_boe[xt];
-        const float same = (x0 == xt) ? 1.0f : 0.0f;
-        float pr[L::V], Sf = 0, Rp = 0;
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          const float f2 = fmaf(bdo[v], zz[u][v], boe[v]);
-          pr[v] = boe[v] * fast_rcp(f2);                // boe_j / f2_j
-          Sf += (L::VEC || L::cls(g, v) < K) ? f2 : 0.0f;
-          if constexpr (GRAD) Rp = fmaf(pr[v], bo[v], Rp);
-        }
-        Sf = group_sum<L::G>(Sf);
-        if constexpr (GRAD) Rp = group_sum<L::G>(Rp);
-        const float pi_x0 = fast_exp2(fmaf(sp0[u], LOG2E, mneg)) * inv, pi_xt = fast_exp2(fmaf(spt[u], LOG2E, mneg)) * inv;
-        const float f2_x0 = fmaf(bdo_x0, pi_x0, boe_x0), f2_xt = fmaf(bdo_xt, pi_xt, boe_xt);
-        const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
-        const float b_x0 = boe_x0 + bdo_x0, b_xt = fmaf(same, bdo_xt, boe_xt);
-        const float a_x0 = fmaf(same, da, a_o);
-        const float Zt = fmaf(a_o, sum_boe + bdo_x0, da * b_xt);
-        const float Zm = fmaf(a_o, Sf, da * f2_xt);
-        const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
-        const float zr = Zm * izt;
-        const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
-        float h[L::V], S1 = 0, D = 0;
-#pragma unroll
-        for (int v = 0; v < L::V; ++v) {
-          S1 = fmaf(boe[v], fast_log2(pr[v] * zr), S1);       // masked slots: boe = 1 but pr * zr != 1
-          if constexpr (!L::VEC) S1 = (L::cls(g, v) < K) ? S1 : S1 - fast_log2(pr[v] * zr);
-          if constexpr (GRAD) {
-            h[v] = fmaf(-A2, pr[v], A1) * bdo[v];
-            D = fmaf(zz[u][v], h[v], D);
-          }
-        }
-        S1 = group_sum<L::G>(S1);
-        if constexpr (GRAD) D = group_sum<L::G>(D);
-        float kls = a_o * S1;
-        kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
-        kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
-        kls = fmaf((1.0f - same) * da * boe_xt, fast_log2(boe_xt * rf_xt * zr), kls);
-        acc_vb = fmaf(tok, kls * izt, acc_vb);
-        if constexpr (GRAD) {
-          const float d_x0 = -A2 * bdo_x0 * rf_x0;                       // added to gf2 at class x0
-          const float d_xt = w_vb * da * (izm - b_xt * rf_xt * izt);     // added to gf2 at class x_t
-          const float bo_x0 = boe_x0 - eps, bo_xt = boe_xt - eps;
-          const float R = fmaf(A1, sum_bo, fmaf(-A2, Rp, fmaf(d_x0, bo_x0, d_xt * bo_xt)));
-          const float p0 = pi_x0 * d_x0 * bdo_x0, pt = pi_xt * d_xt * bdo_xt;
-          const float dot = R + D + p0 + pt;
-          const float C = R - dot + w_ce;
-          const float add0 = p0 - w_ce + same * pt, addt = (1.0f - same) * pt;
-#pragma unroll
-          for (int v = 0; v < L::V; ++v) {
-            const float patch = (d0 == v * CS) ? add0 : ((dt == v * CS) ? addt : 0.0f);
-            gz[v] = fmaf(zz[u][v], h[v] + C, patch);
-          }
-        }
-      }
+    if (!work) break;
+    // ---- phase B
+    x0 = (int)min((unsigned)x0, (unsigned)(KC - 1));      // out-of-range tokens are clamped: nothing faults
+    xt = (int)min((unsigned)xt, (unsigned)(KC - 1));
+    const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
+    const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
+    const bool live = base + lane < p1;
+    const float ce_bits = fmaf(m - z_x0, LOG2E, l2s);     // -log2 softmax(z)[x0]
+    acc_ce += live ? ce_bits : 0.0f;
+    float add0 = 0, addt = 0;
+    if (!need_post) {
+      acc_vb += live ? ce_bits : 0.0f;
       if constexpr (GRAD) {
-#ifdef D3PM_PLAIN_STORES
-        store_slots_off<L>(drow, pos * row_bytes, g, K, gz);
-#else
-        store_slots_off_nt<L>(drow, pos * row_bytes, g, K, gz);
-#endif
-        if (!L::VEC && ld > K) zero_tail<L>(reinterpret_cast<float*>(drow + (size_t)pos * row_bytes), g, K, ld);
-      }
-      // this slot's row of the next round
-      const unsigned nxt = pos + NT * tpp;
-      if (nxt < p1) { issue_tokens(u, nxt); issue_row(u, nxt); }
-      if (u == 0 && pos0 == pbeg) D3PM_TL(6);
-    }
-    if (pos0 - slot + NT * tpp >= p1) break;          // uniform over the workgroup
+        const float w = (t == 0 ? w_vb : 0.0f) + w_ce, wi = w * inv;
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
-      if (pos0 + (NT + u) * tpp < p1) issue_special(u, pos0 + (NT + u) * tpp);
+        for (int j = 0; j < KC; ++j) e[j] *= wi;
+        add0 = -w;
+      }
+    } else {
+      const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt], da = a_d - a_o;
+      const float boe_x0 = s_tab[wave][2][x0], boe_xt = s_tab[wave][2][xt];
+      const float same = (x0 == xt) ? 1.0f : 0.0f;
+      const float bdoi = bdo * inv;
+      const float pi_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)) * inv, pi_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg)) * inv;
+      const float f2_x0 = fmaf(bdo, pi_x0, boe_x0), f2_xt = fmaf(bdo, pi_xt, boe_xt);
+      const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
+      const float b_x0 = boe_x0 + bdo, b_xt = fmaf(same, bdo, boe_xt);
+      const float a_x0 = fmaf(same, da, a_o);
+      const float Zt = fmaf(a_o, sum_boe + bdo, da * b_xt);
+      const float Zm = fmaf(a_o, sum_boe + bdo, da * f2_xt);        // sum_j f2_j = sum_boe + bdo sum_j pi_j
+      const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
+      const float zr = Zm * izt;
+      float pr[KC], E = 0, S1 = 0;
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const float f2 = fmaf(e[j], bdoi, boe[j]);
+        pr[j] = boe[j] * fast_rcp(f2);                      // boe_j / f2_j
+        S1 = fmaf(boe[j], fast_log2(pr[j] * zr), S1);
+        if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
+      }
+      float kls = a_o * S1;
+      kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
+      kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
+      kls = fmaf((1.0f - same) * da * boe_xt, fast_log2(boe_xt * rf_xt * zr), kls);
+      acc_vb += live ? kls * izt : 0.0f;
+      if constexpr (GRAD) {
+        const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
+        const float d_x0 = -A2 * bdo * rf_x0;                          // added to gf2 at class x0
+        const float d_xt = w_vb * da * (izm - b_xt * rf_xt * izt);     // added to gf2 at class x_t
+        const float p0 = pi_x0 * d_x0 * bdo, pt = pi_xt * d_xt * bdo;  // pi_j * (extra g pi_j) at x0, x_t
+        // <pi, g pi> without R: bdo (A1 sum pi - A2 sum pi_j pr_j) + p0 + pt
+        const float D = bdo * (A1 - A2 * inv * E);
+        const float Cc = w_ce - (D + p0 + pt);
+        const float nA2i = -A2 * bdoi, Ci = inv * fmaf(bdo, A1, Cc);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) e[j] *= fmaf(nA2i, pr[j], Ci);
+        add0 = p0 - w_ce;
+        addt = pt;
+      }
+    }
+    D3PM_TL_AFTER(5, e[KC - 1]);
+    if constexpr (GRAD) {
+      // ---- gradient row back through the LDS image; the two special classes are patched in the lane's own row
+#pragma unroll
+      for (int j = 0; j < C::PIECES; ++j)
+        *reinterpret_cast<v4f_nt*>(myrow + 16 * j) = v4f_nt{e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]};
+      *reinterpret_cast<float*>(myrow + 4 * x0) += add0;
+      *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
+      wave_lds_fence();
+#ifdef D3PM_TIMELINE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      D3PM_TL(6);
+#endif
+      const unsigned nrows = p1 - base;       // rows of this wave that exist
+#pragma unroll
+      for (int h = 0; h < C::PIECES; ++h) {
+        const unsigned q = h * 64 + lane, r = q / C::PIECES, j = q % C::PIECES;
+        const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + r * C::STRIDE + j * 16);
+        if (r < nrows)
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * C::RB + j * 16)));
+      }
+      D3PM_TL(7);
+    }
+    D3PM_TL(8);
+    if (base + blockDim.x >= p1) break;       // (uniform over the wave)
+    wave_lds_fence();
+    issue(base + blockDim.x);
   }
-  D3PM_TL(7);
-  // workgroup sums (fixed order: lanes by butterfly, waves in index order)
   acc_vb = wave_sum(acc_vb);
   acc_ce = wave_sum(acc_ce);
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
+  const int nw = blockDim.x >> 6;
+  if (lane == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float svb = 0, sce = 0;
@@ -862,7 +852,6 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss2(
       out.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
     }
   }
-  D3PM_TL(8);
   D3PM_TL_FLUSH;
 }
 
@@ -1271,6 +1260,63 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
   float* partials = (float*)workspace;
   const size_t partial_bytes = workspace_bytes;
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits));
+  static const int version = getenv("D3PM_LOSS_V") ? atoi(getenv("D3PM_LOSS_V")) : 3;
+  const int K = tb->K;
+  if (version == 3 && vec && (K == 8 || K == 16 || K == 24 || K == 32)) {
+    // one token per lane
+    ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, 1);
+    int block;
+    if (B >= 192) {
+      const long want = ((npos + 63) / 64) * 64;
+      block = (int)(want > 512 ? 512 : want);      // (1024 threads leave 128 registers a lane: spills)
+      a.chunks = 1;
+      a.chunk_pos = npos;
+    } else {
+      block = 256;
+      const TokenGrid tg = token_grid(B, npos, block, 1024);
+      a.chunks = tg.chunks;
+      a.chunk_pos = tg.chunk_pos;
+    }
+    if (a.chunks > 1) {
+      const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+      D3PM_CHECK_ARG(partials && partial_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      o.part = partials;
+    }
+    auto launch_t = [&](auto kc, auto grad, auto maxt) -> int {
+      constexpr int KC = decltype(kc)::value;
+      auto kern = k_hybrid_loss_tpl<KC, decltype(grad)::value, decltype(maxt)::value>;
+      const size_t sh = (size_t)(block / 64) * 64 * TplCfg<KC>::STRIDE;
+      if (sh > 48 * 1024) {
+        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      }
+      hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale,
+                         grad_out, o, dlogits);
+      D3PM_LAUNCH_CHECK("k_hybrid_loss_tpl");
+      return D3PM_OK;
+    };
+    auto launch = [&](auto kc, auto grad) -> int {
+      return block <= 512 ? launch_t(kc, grad, std::integral_constant<int, 512>{})
+                          : launch_t(kc, grad, std::integral_constant<int, 1024>{});
+    };
+    auto by_grad = [&](auto kc) -> int {
+      return dlogits ? launch(kc, std::true_type{}) : launch(kc, std::false_type{});
+    };
+    int rc;
+    switch (K) {
+      case 8: rc = by_grad(std::integral_constant<int, 8>{}); break;
+      case 16: rc = by_grad(std::integral_constant<int, 16>{}); break;
+      case 24: rc = by_grad(std::integral_constant<int, 24>{}); break;
+      default: rc = by_grad(std::integral_constant<int, 32>{}); break;
+    }
+    if (rc) return rc;
+    if (a.chunks > 1) {
+      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, o, B, a.chunks, npos, loss_type,
+                         hybrid_coeff, 1.0f);
+      D3PM_LAUNCH_CHECK("k_loss_finalize");
+    }
+    return D3PM_OK;
+  }
   return dispatch_layout_wide(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, L::G);
@@ -1298,20 +1344,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       o.part = partials;
     }
     const dim3 grid(B * a.chunks), blk(block);
-    static const int version = getenv("D3PM_LOSS_V") ? atoi(getenv("D3PM_LOSS_V")) : 2;
-    if (version == 2) {
-      auto go = [&](auto grad, auto maxt) {
-        hipLaunchKernelGGL((k_hybrid_loss2<L, decltype(grad)::value, decltype(maxt)::value>), grid, blk, 0, s, a, logits,
-                           ld, loss_type, hybrid_coeff, grad_scale, grad_out, o, dlogits);
-      };
-      if (block <= 512) {
-        if (dlogits) go(std::true_type{}, std::integral_constant<int, 512>{});
-        else go(std::false_type{}, std::integral_constant<int, 512>{});
-      } else {
-        if (dlogits) go(std::true_type{}, std::integral_constant<int, 1024>{});
-        else go(std::false_type{}, std::integral_constant<int, 1024>{});
-      }
-    } else if (dlogits)
+    if (dlogits)
       hipLaunchKernelGGL((k_hybrid_loss<L, true>), grid, blk, 0, s, a, logits, ld, loss_type, hybrid_coeff, grad_scale,
                          grad_out, o, dlogits);
     else

@@ -64,9 +64,10 @@ tl = buf[:B].astype(np.int64)
 SHADER = "SHADERCLK" in os.environ.get("D3PM_LIB", "")   # per-wave shader-clock ticks instead of global microseconds
 names = ["start", "t loaded", "digest rows arrived", "after barrier", "loop entry", "first row + specials arrived",
          "first token pass done", "loop exit", "kernel end"]
-if os.environ.get("D3PM_LOSS_V", "2") == "2":       # the two-phase kernel records these points instead
-    names = ["start", "t loaded", "tokens + specials arrived", "phase A token 0 done", "phase A done",
-             "digests staged (after barrier)", "phase B token 0 done", "phase B done", "kernel end"]
+if os.environ.get("D3PM_LOSS_V", "3") == "3":       # the token-per-lane kernel
+    names = ["start", "t loaded", "rows arrived, staged in LDS", "phase A done", "tables staged",
+             "phase B arithmetic done", "gradient rows in LDS, patched", "coalesced pieces read back",
+             "global stores issued"]
 nw = int((tl[0, :, 0] != 0).sum())
 t0 = tl[:, :nw, 0].min()
 print(f"{nw} waves per workgroup; median over workgroups, microseconds from the earliest start, one column per wave")
