@@ -6,6 +6,9 @@
 // temporaries into O(K) work per token:
 //   s_j = sum_i p_i^2 Qm[i,j] = off_j * (S2 - p_j^2) + diag_j * p_j^2.
 #include "layout.h"
+#include "rowimage.h"
+
+#include <cstdlib>
 
 namespace d3pm {
 
@@ -277,6 +280,235 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
   if (threadIdx.x == 0) part[(size_t)b * a.chunks + chunk] = s;
 }
 
+// ------------------------------------------------------------------ LVB loss, one token per lane, float32
+// The training form of the loss (a gradient is asked for): every lane takes a whole token, rows go through a
+// wave-private LDS image (rowimage.h), per-class constants of the timestep are wave-uniform scalars, and the
+// arithmetic after the softmax is float32 in a form that does not cancel:
+//   e_j = 2^(z_j - max),  E2 = sum e_j^2,  s'_j = s_j / S2 = mo_j + (mdo / E2) e_j^2
+// (S2 = sum p_i^2 divides out of every ratio; mdo = diag - off of Qbar_{t-1} is one value for all classes because
+// every row of the table has the same sum, so sum_j s'_j = sum_mo + mdo needs no reduction), and with
+// c = rsum' / den the Kullback-Leibler term of a token is
+//   sum_j post_j log(post_j / P_j),   post_j / P_j = B_j c / s'_j
+// -- every logarithm is of a ratio that is close to one wherever post_j is large.  Every class is first treated
+// as a generic one (A_j = a_off, B_j = mo_j); the classes x0 (B = mo + mdo) and x_t (A = a_diag) are corrected
+// with per-token scalars (their two logarithms in a 1 + d form, see below) and patched into the lane's own LDS row.
+// The MSA variant takes its denominator from another table (losses.py:148), for which that form does not hold: it
+// stays with the float64 kernel.  Gradient:
+//   gs_j = A_j cs / S2 (psum / rsum' - B_j / (den s'_j)) = g0 - g1 q_j (+ d0 at x0, + dt at x_t),  q_j = mo_j / s'_j
+//   W = sum_j gs_j mo_j,  dot = 2 (W S2 + mdo sum_i p_i^2 gs_i),  gz_i = 2 p_i^2 (W + mdo gs_i) - p_i dot.
+// The sequence sums are accumulated in float64.  Forward-only evaluation (ELBO scoring, where differences of
+// nearly equal sums are taken) stays with the float64 kernel above.
+// log2(1 + d) to float32 relative accuracy for any d > -1 (for small d the rounding of 1 + d is divided out).
+__device__ __forceinline__ float log2_1p(float d) {
+  // log(1 + d) = log(w) + (d - (w - 1)) / w with w = fl(1 + d); the correction is at most one rounding of w, so its
+  // division by w is dropped (that changes the result by less than 6e-8 |d|)
+  d = fmaxf(d, -0.99999994f);          // a class of zero weight (d = -1) keeps a finite logarithm: 0 * finite = 0
+  const float w = 1.0f + d;
+  return fmaf(d - (w - 1.0f), 1.44269504088896340736f, __builtin_amdgcn_logf(w));
+}
+
+template <int K, int LD>
+__global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* __restrict__ pred,
+                                                      const double* __restrict__ q, int tmax, int msa, float grad_scale,
+                                                      double log_prior, double* __restrict__ part,
+                                                      double* __restrict__ per_seq, float* __restrict__ dpred) {
+  using Img = RowImage<LD>;
+  constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
+  extern __shared__ __align__(16) char lvb_rows[];          // [waves][64][STRIDE]
+  __shared__ double red[8];
+  __shared__ float s_tab[8][5][32];                         // per wave: a_diag, a_off (Q_t), mo, den diag / off
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
+  const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
+  const char* __restrict__ prow = (const char*)(pred + (size_t)b * a.npos * LD);
+  char* __restrict__ drow = (char*)(dpred + (size_t)b * a.npos * LD);
+  const int64_t* __restrict__ x0row = a.x0 + (size_t)b * a.npos;
+  const int64_t* __restrict__ xtrow = a.xt + (size_t)b * a.npos;
+  char* const img = lvb_rows + (size_t)wave * Img::BYTES;
+  char* const myrow = img + lane * Img::STRIDE;
+  Img rows;
+  int x0 = 0, xt = 0;
+  auto issue = [&](unsigned base) {
+    const unsigned last = p1 - 1 - base, mine = min((unsigned)lane, last);
+    x0 = (int)x0row[base + mine];
+    xt = (int)xtrow[base + mine];
+    rows.request(prow, base, last, lane);
+  };
+  unsigned base = pbeg + wave * 64;
+  if (base < p1) issue(base);
+  int t = (int)a.t[b];
+  t = max(1, min(t, max(tmax, a.tb.T - 1)));                 // t outside [1, T) would read outside the digests
+  const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
+  float mo[K];
+  float mdo = 0, sum_mo = 0;
+  if (branch == 2) {
+    const int tm = min(t - 1, a.tb.T - 1), tq = min(t, a.tb.T - 1), td = msa ? tm : tq;
+    const float vd = lane < K ? (float)dgd(a.tb.qbar_digest, tm, 0, K)[lane] : 0.0f;
+    const float vo = lane < K ? (float)dgd(a.tb.qbar_digest, tm, 1, K)[lane] : 0.0f;
+    if (lane < K) {
+      s_tab[wave][0][lane] = (float)dgd(a.tb.qone_digest, tq, 0, K)[lane];
+      s_tab[wave][1][lane] = (float)dgd(a.tb.qone_digest, tq, 1, K)[lane];
+      s_tab[wave][2][lane] = vo;
+      s_tab[wave][3][lane] = (float)dgd(a.tb.qbar_digest, td, 0, K)[lane];
+      s_tab[wave][4][lane] = (float)dgd(a.tb.qbar_digest, td, 1, K)[lane];
+    }
+    mdo = lane_broadcast(vd - vo, 0);
+    sum_mo = wave_sum(lane < K ? vo : 0.0f);
+#pragma unroll
+    for (int j = 0; j < K; ++j) mo[j] = lane_broadcast(vo, j);
+  }
+  const float cs = grad_scale / (float)a.npos;
+  double acc = 0;
+  for (;; base += blockDim.x) {
+    if (base >= p1) break;                                   // (uniform over the wave)
+    const bool live = base + lane < p1;
+    x0 = (int)min((unsigned)x0, (unsigned)(K - 1));          // out-of-range tokens are clamped: nothing faults
+    xt = (int)min((unsigned)xt, (unsigned)(K - 1));
+    float e[LD];
+    float tok_loss = 0, add0 = 0, addt = 0;
+    if (branch == 1) {
+      // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
+      if (live) {
+        const double* qq = q + ((size_t)b * a.npos + base + lane) * K;
+        double s = 0;
+        for (int j = 0; j < K; ++j) s += (qq[j] > 0.0 ? qq[j] * log(qq[j]) : 0.0) - qq[j] * log_prior;
+        // 'batchmean' divides by the leading size of q[i]: L for a sequence (the final division), but only the
+        // depth D for an MSA laid out [D,L,K]
+        acc += s * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
+      }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) e[j] = 0.0f;
+    } else {
+      rows.deposit(img, lane);
+      wave_lds_order();
+      Img::read_row(img, lane, e);
+      const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
+      constexpr int KS = LD;                                 // classes of the softmax of this branch
+      if (branch == 0) {
+        // CrossEntropyLoss over all LD logits (losses.py:54)
+        float m = e[0];
+#pragma unroll
+        for (int j = 1; j < KS; ++j) m = fmaxf(m, e[j]);
+        const float mneg = -m * LOG2E;
+        float s = 0;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
+        tok_loss = fmaf(__builtin_amdgcn_logf(s), LN2, m - z_x0);
+        const float wi = cs * __builtin_amdgcn_rcpf(s);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) e[j] *= wi;
+        add0 = -cs;
+      } else {
+        const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
+        float m = e[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j) m = fmaxf(m, e[j]);
+        const float mneg = -m * LOG2E;
+        float s = 0, R0 = 0;                                   // R0 = sum of e_j^2 over the classes other than x0
+        float e2[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg));
+          s += e[j];
+          e2[j] = e[j] * e[j];
+          R0 += (j == x0) ? 0.0f : e2[j];
+        }
+        const float e_x0 = __builtin_amdgcn_exp2f(fmaf(z_x0, LOG2E, mneg)), e_xt = __builtin_amdgcn_exp2f(fmaf(z_xt, LOG2E, mneg));
+        const float E2 = fmaf(e_x0, e_x0, R0);
+        const float inv = __builtin_amdgcn_rcpf(s), inv2 = inv * inv;
+        const float S2 = E2 * inv2;
+        const float c3 = mdo * __builtin_amdgcn_rcpf(E2);
+        const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt], da = a_d - a_o;
+        const float mo_x0 = s_tab[wave][2][x0], mo_xt = s_tab[wave][2][xt];
+        const bool same_b = x0 == xt;
+        const float same = same_b ? 1.0f : 0.0f;
+        const float den = same_b ? s_tab[wave][3][xt] : s_tab[wave][4][xt];
+        const float iden = __builtin_amdgcn_rcpf(den);
+        const float w1 = c3 * R0, w2 = c3 * e_xt * e_xt;             // b_x0 - s'_x0 and s'_xt - mo_xt, both >= 0
+        const float sp_x0 = fmaf(e_x0 * e_x0, c3, mo_x0), sp_xt = mo_xt + w2;                     // s'_x0, s'_xt
+        const float Sm = a_o * (sum_mo + mdo);
+        const float rs = fmaf(da, sp_xt, Sm);                        // rsum' (sum_j s'_j = sum_mo + mdo)
+        // Every ratio post_j / P_j = mo_j rs / (s'_j den) is taken as 1 + d_j with
+        //   d_j = (mo_j (rs - den) - (mdo / E2) e_j^2 den) / (s'_j den),
+        // rs - den = da w2 (x0 != x_t) or -da w1 (x0 == x_t) known without cancellation (den = Sm + da B_xt, the way
+        // Qbar_t is built from Qbar_{t-1}): the first-order parts of the terms cancel in the sum over classes, so a
+        // logarithm of the rounded ratio (6e-8 absolute) would leave an error of that size in a sum that can be
+        // far smaller.
+        const float Dl = same_b ? -da * w1 : da * w2, cdn = -c3 * den;
+        float qv[K], G1 = 0, Hq = 0, Hp = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float sp = fmaf(e2[j], c3, mo[j]);
+          const float r = __builtin_amdgcn_rcpf(sp);
+          qv[j] = mo[j] * r;                                          // mo_j / s'_j
+          const float d = fmaf(e2[j], cdn, mo[j] * Dl) * (r * iden);
+          G1 = fmaf(mo[j], log2_1p(d), G1);
+          Hq = fmaf(mo[j], qv[j], Hq);
+          Hp = fmaf(e2[j], qv[j], Hp);
+        }
+        // special classes: x0 has B = mo + mdo, x_t has A = a_diag (both at once when x0 == x_t)
+        const float r_x0 = __builtin_amdgcn_rcpf(sp_x0), r_xt = __builtin_amdgcn_rcpf(sp_xt);
+        const float b_x0 = mo_x0 + mdo, a_x0 = fmaf(same, da, a_o);
+        // class x0 as a generic class (the same expression as in the loop, so that its term there is cancelled bit
+        // for bit), then with its own B = mo + mdo; class x_t with A = a_diag.  Their d without cancellation:
+        //   x0 == x_t:  d0 = w1 Sm / (s'_x0 den)
+        //   otherwise:  d0 = (w1 den + da w2 b_x0) / (s'_x0 den),   dt = -w2 Sm / (s'_xt den)
+        const float lg_x0 = log2_1p(fmaf(e_x0 * e_x0, cdn, mo_x0 * Dl) * (r_x0 * iden));
+        const float d0r = (same_b ? w1 * Sm : fmaf(w1, den, da * w2 * b_x0)) * r_x0 * iden;
+        const float dtr = -w2 * Sm * r_xt * iden;
+        const float lb_x0 = log2_1p(d0r);
+        const float lg_xt = log2_1p(dtr);
+        float kl = a_o * G1;
+        kl = fmaf(-a_o * mo_x0, lg_x0, kl);
+        kl = fmaf(a_x0 * b_x0, lb_x0, kl);
+        kl = fmaf((1.0f - same) * da * mo_xt, lg_xt, kl);
+        tok_loss = kl * iden * LN2;                                  // logarithms above are base 2
+        // gradient
+        const float b_xt = fmaf(same, mdo, mo_xt);
+        const float psum = iden * fmaf(a_o, sum_mo + mdo, da * b_xt);
+        const float iS2 = __builtin_amdgcn_rcpf(S2), irs = __builtin_amdgcn_rcpf(rs);
+        const float k = cs * iS2;
+        const float g0 = a_o * k * psum * irs, g1 = a_o * k * iden;
+        const float gx0 = a_x0 * k * (psum * irs - b_x0 * iden * r_x0);          // exact gs at x0
+        const float d0 = gx0 - (g0 - g1 * mo_x0 * r_x0);
+        const float gxt = a_d * k * (psum * irs - mo_xt * iden * r_xt);          // exact gs at x_t (x_t != x0)
+        const float dt = (1.0f - same) * (gxt - (g0 - g1 * mo_xt * r_xt));
+        const float pp_x0 = e_x0 * e_x0 * inv2, pp_xt = e_xt * e_xt * inv2;
+        const float W = fmaf(g0, sum_mo, fmaf(-g1, Hq, fmaf(d0, mo_x0, dt * mo_xt)));
+        const float Sg = fmaf(inv2, fmaf(g0, E2, -g1 * Hp), fmaf(pp_x0, d0, pp_xt * dt));    // sum_i p_i^2 gs_i
+        const float dot = 2.0f * fmaf(W, S2, mdo * Sg);
+        const float c4 = 2.0f * inv2 * fmaf(mdo, g0, W), c5 = 2.0f * inv2 * mdo * g1, c6 = inv * dot;
+#pragma unroll
+        for (int j = 0; j < K; ++j) e[j] = fmaf(e2[j], fmaf(-c5, qv[j], c4), -c6 * e[j]);
+#pragma unroll
+        for (int j = K; j < LD; ++j) e[j] = 0.0f;
+        add0 = 2.0f * pp_x0 * mdo * d0;
+        addt = 2.0f * pp_xt * mdo * dt;
+      }
+      acc += live ? (double)tok_loss : 0.0;
+    }
+    // gradient rows back through the image; the special classes are patched in the lane's own row
+    Img::write_row(img, lane, e);
+    *reinterpret_cast<float*>(myrow + 4 * x0) += add0;
+    *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
+    wave_lds_order();
+    Img::store(img, drow, base, p1 - base, lane);
+    if (base + blockDim.x >= p1) break;
+    wave_lds_order();
+    issue(base + blockDim.x);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sacc = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sacc += red[w];
+    if (a.chunks == 1) per_seq[b] = sacc / (double)a.npos;
+    else part[(size_t)b * a.chunks + chunk] = sacc;
+  }
+}
+
 __global__ void k_lvb_finalize(const double* __restrict__ part, int B, int chunks, long npos,
                                double* __restrict__ per_seq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,6 +751,50 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
   hipStream_t s = (hipStream_t)stream;
   // sample_prior builds a float32 1/K and takes its float32 log (losses.py:11-12,60)
   const double log_prior = (double)logf(1.0f / (float)tb->K);
+  // training form: one token per lane, float32 (K = 22 with rows of 22 or 24 logits, the two alphabets of the
+  // reference's denoisers); everything else, and forward-only evaluation, on the float64 kernel
+  static const bool allow_tpl = !(getenv("D3PM_LVB_F64") && atoi(getenv("D3PM_LVB_F64")));
+  if (allow_tpl && dpred && msa == 0 && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+      ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
+    ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
+    int block;
+    if (B >= 192) {
+      const long want = ((npos + 63) / 64) * 64;
+      block = (int)(want > 512 ? 512 : want);
+      a.chunks = 1;
+      a.chunk_pos = npos;
+    } else {
+      block = 256;
+      const TokenGrid tg = token_grid(B, npos, block, 1024);
+      a.chunks = tg.chunks;
+      a.chunk_pos = tg.chunk_pos;
+    }
+    double* part = (double*)workspace;
+    if (a.chunks > 1) {
+      const size_t need = (size_t)B * a.chunks * sizeof(double);
+      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    }
+    auto go = [&](auto ldc) -> int {
+      constexpr int LDC = decltype(ldc)::value;
+      auto kern = k_lvb_loss_tpl<22, LDC>;
+      const size_t sh = (size_t)(block / 64) * RowImage<LDC>::BYTES;
+      if (sh > 48 * 1024) {
+        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      }
+      hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, pred, q, tmax, msa, (float)grad_scale,
+                         log_prior, part, per_seq, dpred);
+      D3PM_LAUNCH_CHECK("k_lvb_loss_tpl");
+      return D3PM_OK;
+    };
+    const int rc = ld == 22 ? go(std::integral_constant<int, 22>{}) : go(std::integral_constant<int, 24>{});
+    if (rc) return rc;
+    if (a.chunks > 1) {
+      hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);
+      D3PM_LAUNCH_CHECK("k_lvb_finalize");
+    }
+    return D3PM_OK;
+  }
   auto run = [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, L::G);

@@ -188,6 +188,59 @@ def test_seeded_against_oracle_odd_shapes(pkg):
             close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
 
 
+def _oracle_process(betas, kind, K, lam):
+    """`im.build_process` for any K (the reference only builds K = 2 ** num_bits)."""
+    one = im._onestep_uniform if kind == "uniform" else im._onestep_absorbing
+    steps = [one(betas[t], K, None) if kind == "uniform" else one(betas[t], K) for t in range(betas.shape[0])]
+    onestep = torch.stack(steps)
+    cur, chain = onestep[0].numpy(), []
+    for t in range(betas.shape[0]):
+        cur = cur if t == 0 else np.tensordot(cur, onestep[t].numpy(), axes=[[1], [0]])
+        chain.append(cur)
+    return im.Process(betas=betas, kind=kind, K=K, bands=None, q_mats=torch.tensor(np.stack(chain)),
+                      qT_onestep=onestep.permute(0, 2, 1), hybrid_coeff=lam, loss_type="hybrid")
+
+
+@pytest.mark.parametrize("K", [8, 16, 24, 32])
+@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (1, 64)])
+def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
+    """The fused loss kernel that gives every lane a whole token (structured tables, K in {8, 16, 24, 32}, rows
+    16-byte aligned): ragged last wave, several rounds per workgroup, chunked small batches and one workgroup per
+    batch element, t = 0 rows, weighted upstream gradient -- against the CPU oracle; K = 24 through the C ABI on
+    tables passed in (the facade only builds K = 2 ** num_bits)."""
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
+    from d3pm_amd.tables import ImageTables
+    T, lam = 12, 0.01
+    betas = pkg.generate_betas(0.02, 0.5, T, "linear")
+    for kind in ("uniform", "absorbing"):
+        p = _oracle_process(betas, kind, K, lam)
+        tb = ImageTables(p.q_mats.to(DEV), p.qT_onestep.to(DEV), transposed_onestep=True)
+        assert tb.structured
+        gen = torch.Generator().manual_seed(K * 1000 + B + npos)
+        x0 = torch.randint(0, K, (B, npos, 1, 1), generator=gen)
+        t = torch.randint(0, T, (B,), generator=gen, dtype=torch.int32)
+        t[0] = 0
+        noise = torch.rand(B, npos, 1, 1, K, generator=gen)
+        logits = (2.0 * torch.randn(B, npos, 1, 1, K, generator=gen)).requires_grad_(True)
+        w = torch.rand(B, generator=gen) + 0.5
+        xt = im.forward_sample(p, x0, t, noise)
+        loss_ref = im.losses_given_xt(p, logits, x0, xt, t)
+        (loss_ref * w).sum().backward()
+        lg, x0d, xtd, td, wd = (a.detach().to(DEV).contiguous() for a in (logits, x0, xt, t, w))
+        vb, ce, loss = (torch.empty(B, device=DEV) for _ in range(3))
+        dl = torch.full_like(lg, float("nan"))
+        wsb = lib.d3pm_hybrid_loss_workspace(B, npos, K)
+        ws = torch.empty(max(wsb // 4, 1), device=DEV)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0d), 8, ptr(xtd), 8, ptr(td), 4, B, npos, LOSS["hybrid"],
+                                   lam, 1.0, ptr(wd), ptr(vb), ptr(ce), ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb,
+                                   stream_ptr()))
+        torch.cuda.synchronize()
+        close(loss, loss_ref.detach().numpy(), atol=1e-6, what=f"loss {kind} K={K}")
+        close(vb + lam * ce, loss_ref.detach().numpy(), atol=1e-6, what=f"vb + lam ce {kind} K={K}")
+        ref = logits.grad.numpy()
+        close(dl, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
+
+
 @pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
 def test_k256_matrix_core_tiles_against_oracle(pkg, B, L):
     """K = 256 runs its contractions on the matrix cores in tiles of 64 tokens:
