@@ -696,6 +696,111 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
   }
 }
 
+// ------------------------------------------------------------------ reverse step, device noise, one token per lane
+// As k_lvb_reverse_device_noise (float32 marginal, one uniform per token, nothing to match bit for bit), with a
+// whole token per lane: rows through the wave-private LDS image, per-class constants in scalar registers, and the
+// inverse CDF a running sum inside the lane -- no cross-lane scan at all.  With e_j = 2^(z_j - max) and
+// s'_j = mo_j + (mdo / sum e^2) e_j^2 the unnormalised marginal is A_j s'_j; the factor a_off is divided out, which
+// leaves generic weights g_j = s'_j and an extra mass X = (a_diag / a_off - 1) g_xt on class x_t.  One uniform
+// decides both: target = u (G + X); target < X picks x_t, otherwise the generic scan runs with target - X.
+// The last class (the gap of an MSA) has its weight divided by `last_class_div`, or removed in the query row.
+template <int K, int LD>
+__global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float* __restrict__ pred, uint64_t seed,
+                                                         uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                         float last_class_div, long exclude_last_prefix,
+                                                         int64_t* __restrict__ out) {
+  using Img = RowImage<LD>;
+  constexpr float LOG2E = 1.44269504088896340736f;
+  extern __shared__ __align__(16) char rev_rows[];          // [waves][64][STRIDE]
+  __shared__ float s_tab[8][3][32];                         // per wave: a_diag, a_off of Q_t by x_t; mo by class
+  if (offset_dev) offset += *offset_dev;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
+  const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
+  const char* __restrict__ prow = (const char*)(pred + (size_t)b * a.npos * LD);
+  const int64_t* __restrict__ xtrow = a.xt + (size_t)b * a.npos;
+  int64_t* __restrict__ orow = out + (size_t)b * a.npos;
+  char* const img = rev_rows + (size_t)wave * Img::BYTES;
+  Img rows;
+  int xt = 0;
+  auto issue = [&](unsigned base) {
+    const unsigned last = p1 - 1 - base, mine = min((unsigned)lane, last);
+    xt = (int)xtrow[base + mine];
+    rows.request(prow, base, last, lane);
+  };
+  unsigned base = pbeg + wave * 64;
+  if (base < p1) issue(base);
+  int t = (int)a.t[b];
+  t = max(1, min(t, a.tb.T - 1));                            // t outside [1, T) would read outside the digests
+  const float vd = lane < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[lane] : 0.0f;
+  const float vo = lane < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[lane] : 0.0f;
+  if (lane < K) {
+    s_tab[wave][0][lane] = (float)dgd(a.tb.qone_digest, t, 0, K)[lane];
+    s_tab[wave][1][lane] = (float)dgd(a.tb.qone_digest, t, 1, K)[lane];
+    s_tab[wave][2][lane] = vo;
+  }
+  const float mdo = lane_broadcast(vd - vo, 0);
+  float mo[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) mo[j] = lane_broadcast(vo, j);
+  const float inv_last = 1.0f / last_class_div;
+  wave_lds_order();
+  for (;; base += blockDim.x) {
+    if (base >= p1) break;                                   // (uniform over the wave)
+    const unsigned pos = base + lane;
+    // the uniform of this token: Philox counter = global token index
+    const U4 rnd = philox4x32_10((uint64_t)b * (uint64_t)a.npos + pos, offset, seed);
+    const float u = fmaf((float)(rnd.x >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f);   // in (0, 1)
+    xt = (int)min((unsigned)xt, (unsigned)(K - 1));          // out-of-range tokens are clamped: nothing faults
+    rows.deposit(img, lane);
+    wave_lds_order();
+    float e[LD];
+    Img::read_row(img, lane, e);
+    const float z_xt = *reinterpret_cast<const float*>(img + lane * Img::STRIDE + 4 * xt);
+    float m = e[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) m = fmaxf(m, e[j]);
+    const float mneg = -m * LOG2E;
+    float E2 = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float ej = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg));
+      e[j] = ej * ej;
+      E2 += e[j];
+    }
+    const float c3 = mdo * __builtin_amdgcn_rcpf(E2);
+    const float w_last = (long)pos < exclude_last_prefix ? 0.0f : inv_last;
+    float G = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      e[j] = fmaf(e[j], c3, mo[j]);                          // g_j = s'_j
+      if (j == K - 1) e[j] *= w_last;
+      G += e[j];
+    }
+    const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt];
+    const float e_xt = __builtin_amdgcn_exp2f(fmaf(z_xt, LOG2E, mneg));
+    const float g_xt = fmaf(e_xt * e_xt, c3, s_tab[wave][2][xt]) * (xt == K - 1 ? w_last : 1.0f);
+    const float X = (a_d - a_o) * __builtin_amdgcn_rcpf(a_o) * g_xt;
+    const float target = u * (G + X) - X;                    // < 0: the extra mass of x_t was hit
+    float run = 0;
+    int cnt = 0;                                             // classes whose cumulative weight is <= target
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+      run += e[j];
+      cnt += (run <= target) ? 1 : 0;
+    }
+    int pick = target < 0.0f ? xt : cnt;
+    // rounding can carry the scan onto a class of zero weight (the excluded last class): step back to the last
+    // class that has weight
+    if (pick == K - 1 && w_last == 0.0f) pick = K - 2;
+    if (pos < p1) orow[pos] = pick;
+    if (base + blockDim.x >= p1) break;
+    wave_lds_order();
+    issue(base + blockDim.x);
+  }
+}
+
 static int check_prot(const d3pm_tables_f64* tb, int B, long npos) {
   D3PM_CHECK_ARG(tb && tb->qbar_digest && tb->qone_digest, "tables descriptor or digest is null");
   D3PM_CHECK_ARG(tb->K >= 2 && tb->K <= 256 && tb->T >= 1, "need 2 <= K <= 256, T >= 1 (K=%d, T=%d)", tb->K, tb->T);
@@ -826,6 +931,37 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
   D3PM_CHECK_ARG(npos * ld < 0x1fffffffL, "one batch element spans %ld predictions: more than 2^29", npos * ld);
+  static const bool allow_tpl = !(getenv("D3PM_REV_OLD") && atoi(getenv("D3PM_REV_OLD")));
+  if (allow_tpl && !expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0) {
+    // one token per lane
+    ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, 1);
+    int block;
+    if (B >= 192) {
+      const long want = ((npos + 63) / 64) * 64;
+      block = (int)(want > 512 ? 512 : want);
+      a.chunks = 1;
+      a.chunk_pos = npos;
+    } else {
+      block = 256;
+      const TokenGrid tg = token_grid(B, npos, block, 1024);
+      a.chunks = tg.chunks;
+      a.chunk_pos = tg.chunk_pos;
+    }
+    auto go = [&](auto ldc) -> int {
+      constexpr int LDC = decltype(ldc)::value;
+      auto kern = k_lvb_reverse_tpl<22, LDC>;
+      const size_t sh = (size_t)(block / 64) * RowImage<LDC>::BYTES;
+      if (sh > 48 * 1024) {
+        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      }
+      hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, (hipStream_t)stream, a, pred, seed, offset,
+                         offset_dev, (float)last_class_div, exclude_last_prefix, out);
+      D3PM_LAUNCH_CHECK("k_lvb_reverse_tpl");
+      return D3PM_OK;
+    };
+    return ld == 22 ? go(std::integral_constant<int, 22>{}) : go(std::integral_constant<int, 24>{});
+  }
   if (!expo && ld <= 32) {
     // few lanes per token: the draw is cheap per class, the cross-lane steps are what costs
     static const int rev_blocks = getenv("D3PM_REV_BLOCKS") ? atoi(getenv("D3PM_REV_BLOCKS")) : 1024;
