@@ -188,6 +188,66 @@ def test_reverse_step_device_noise_distribution(pkg, tables500, n_tok):
             assert (np.abs(freq - Pm) < 5 * np.sqrt(Pm * (1 - Pm) / n) + 1e-5).all(), (w_last, freq, Pm)
 
 
+@pytest.mark.parametrize("n_tok", [22, 24])
+def test_reverse_step_device_noise_at_sampler_shape(pkg, tables500, n_tok):
+    """The reverse step at the shape the sampling benchmark runs (1024 sequences x 263 positions, rows of 22 or 24
+    logits; 263 = 4 x 64 + 7 leaves a ragged last wave): every position has its own logits row and x_t, the
+    1024 sequences are its sample; per-position class frequencies against the oracle's marginal."""
+    from d3pm_amd.protein_generation.generate import reverse_step
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    tb = protein_tables(Qt, Qb)
+    Bn, Ln = 1024, 263
+    gen = torch.Generator().manual_seed(17 + n_tok)
+    for t in (499, 250, 2):
+        rows = torch.randn(Ln, n_tok, generator=gen) * 2.0
+        xt = torch.randint(0, 22, (Ln,), generator=gen)
+        P = pr.reverse_marginal(rows, xt, Qt.cpu()[t], Qb.cpu()[t - 1]).numpy()          # [L, K]
+        logits = rows.expand(Bn, Ln, n_tok).contiguous().to(DEV)
+        x = xt.expand(Bn, Ln).contiguous().to(DEV)
+        tt = torch.full((Bn,), t, device=DEV)
+        c = torch.zeros(1, dtype=torch.int64, device=DEV)
+        out = reverse_step(tb, logits, x, tt, rng=(3, 0, c))
+        assert torch.equal(out, reverse_step(tb, logits, x, tt, rng=(3, 0, c)))           # same stream, same draw
+        assert not torch.equal(out, reverse_step(tb, logits, x, tt, rng=(3, 4, c)))
+        assert int(out.min()) >= 0 and int(out.max()) < 22
+        counts = torch.nn.functional.one_hot(out.cpu(), 22).sum(dim=0).numpy()              # [L, K]
+        # exact binomial tails per (position, class) cell -- many cells expect a handful of counts or none, where a
+        # normal approximation is useless; 5786 cells x 3 timesteps x 2 row widths at 1e-9 each
+        from scipy.stats import binom
+        tail = np.minimum(binom.cdf(counts, Bn, P), binom.sf(counts - 1, Bn, P))
+        assert tail.min() > 1e-9, (tail.min(), np.unravel_index(tail.argmin(), tail.shape))
+        # and pooled over positions, where every class has thousands of counts
+        pooled, expect = counts.sum(0) / (Bn * Ln), P.mean(0)
+        assert (np.abs(pooled - expect) < 5 * np.sqrt(expect / (Bn * Ln)) + 1e-6).all(), (pooled, expect)
+        if t == 499:       # a nearly flat marginal: independent draws never coincide over 263 positions
+            assert len({bytes(r) for r in out.cpu().numpy().astype(np.uint8)}) == Bn
+
+
+@pytest.mark.timeout(600)
+def test_graphed_reverse_sampler_full_length(pkg, tables500):
+    """The whole T = 500 loop (499 steps) of 1024 sequences of 263 positions as one HIP graph, as the sampling
+    benchmark replays it: tokens in range, the same seed and start give the same sequences, replays differ."""
+    from d3pm_amd.graphs import GraphedReverseSampler
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    tb = protein_tables(Qt, Qb)
+    Bn, Ln = 1024, 263
+    frozen = torch.randn(Bn, Ln, 22, generator=torch.Generator().manual_seed(1)).to(DEV)
+    model = lambda x, tt: frozen
+    x_init = torch.randint(0, 22, (Bn, Ln), device=DEV)
+    a = GraphedReverseSampler(tb, model, Bn, Ln, 500, DEV, seed=21)
+    b = GraphedReverseSampler(tb, model, Bn, Ln, 500, DEV, seed=21)
+    ya, yb = a.sample(x_init).clone(), b.sample(x_init).clone()
+    assert ya.shape == (Bn, Ln) and int(ya.min()) >= 0 and int(ya.max()) < 22
+    assert torch.equal(ya, yb)
+    ya2 = a.sample(x_init).clone()
+    assert not torch.equal(ya, ya2)
+    # after 499 steps with frozen logits the tokens follow the last steps' marginal, which favours the classes
+    # the logits favour: the most frequent token of a position is among its top logits more often than chance
+    assert (ya == frozen.argmax(dim=-1)).double().mean() > 1.5 / 22
+
+
 def test_generate_msa_replay_golden(pkg):
     from d3pm_amd.protein_generation.generate import generate_msa_d3pm
     g = golden("protein_generate_msa")
