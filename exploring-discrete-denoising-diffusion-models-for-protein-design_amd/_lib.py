@@ -48,6 +48,7 @@ SIGNATURES = {
     "d3pm_q_probs": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _P]),
     "d3pm_q_sample": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _I, _U64, _U64, _P, _P, _P]),
     "d3pm_q_posterior_logits": (_I, [_T32, _P, _I, _L, _I, _P, _I, _P, _I, _I, _L, _P, _P]),
+    "d3pm_q_posterior_logits_backward": (_I, [_T32, _P, _L, _P, _I, _I, _L, _P, _P, _P]),
     "d3pm_hybrid_loss_workspace": (_SZ, [_I, _L, _I]),
     "d3pm_q_sample_draw_t": (_I, [_T32, _P, _I, _I, _L, _U64, _U64, _P, _P, _P, _P, _P]),
     "d3pm_hybrid_loss": (_I, [_T32, _P, _L, _P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _U64,

@@ -284,6 +284,58 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_logits(ImgArgs a, const flo
   }
 }
 
+// ------------------------------------------------------------------ q_posterior_logits, gradient to the x_start logits
+// out_j = log(a_j + eps) + log(f2_j + eps), f2 = softmax(z) Qbar_{t-1}: with G the gradient arriving at `out`,
+//   gf2_j = G_j / (f2_j + eps),  g pi_i = sum_j gf2_j Qbar[i,j] = S + gf2_i (diag_i - off_i),  S = sum_j gf2_j off_j,
+//   gz_i = pi_i (g pi_i - <pi, g pi>);   t == 0: out = z, so gz = G.
+// (what autograd derives from d3pm/diffusion_discrete.py:320-336 in the reference)
+template <class L>
+__global__ __launch_bounds__(BLOCK) void k_posterior_logits_backward(ImgArgs a, const float* __restrict__ xs_logits,
+                                                                     long ld, const float* __restrict__ gout,
+                                                                     float* __restrict__ gz_out) {
+  const int K = a.tb.K;
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
+  const int t = max(0, min(load_tok(a.t, b, a.t_bytes), a.tb.T - 1));
+  Post<L> P;
+  if (t > 0) load_post<L>(a.tb, t, g, P);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
+    const long n = (long)b * a.npos + pos;
+    float z[L::V], G[L::V], r[L::V];
+    load_slots<L>(gout + n * K, g, K, 0.0f, G);
+    if (t == 0) {
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) r[v] = G[v];
+    } else {
+      load_slots<L>(xs_logits + n * ld, g, K, -INFINITY, z);
+      float pi[L::V], zm, zs;
+      group_softmax<L>(z, pi, zm, zs);
+      float S = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        const bool ok = L::VEC || L::cls(g, v) < K;
+        const float f2 = fmaf(P.bd[v] - P.bo[v], pi[v], P.bo[v]);
+        G[v] = ok ? G[v] / (f2 + eps) : 0.0f;                 // gf2
+        S = fmaf(G[v], ok ? P.bo[v] : 0.0f, S);
+      }
+      S = group_sum<L::G>(S);
+      float dot = 0;
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) {
+        G[v] = fmaf(G[v], P.bd[v] - P.bo[v], S);              // g pi
+        dot = fmaf(pi[v], G[v], dot);
+      }
+      dot = group_sum<L::G>(dot);
+#pragma unroll
+      for (int v = 0; v < L::V; ++v) r[v] = pi[v] * (G[v] - dot);
+    }
+    store_slots<L>(gz_out + n * ld, g, K, r);
+    if (ld > K) zero_tail<L>(gz_out + n * ld, g, K, ld);
+  }
+}
+
 // ------------------------------------------------------------------ fused hybrid loss, forward + backward
 // Per token (t > 0), with pi = softmax(z), a = column x_t of Q_t (+eps),
 // Qm = Qbar_{t-1}, b = row x0 of Qm (+eps), f2 = pi Qm + eps:
@@ -1157,6 +1209,29 @@ extern "C" int d3pm_q_posterior_logits(const d3pm_tables_f32* tb, const void* x_
     else
       hipLaunchKernelGGL((k_posterior_logits<L, false>), grid, block, 0, s, a, (const float*)nullptr, ld, out);
     D3PM_LAUNCH_CHECK("k_posterior_logits");
+    return D3PM_OK;
+  });
+}
+
+extern "C" int d3pm_q_posterior_logits_backward(const d3pm_tables_f32* tb, const float* x_start_logits, long ld,
+                                                const void* t, int t_bytes, int B, long npos, const float* grad_out,
+                                                float* grad_logits, void* stream) {
+  if (int rc = check_common(tb, B, npos)) return rc;
+  D3PM_CHECK_ARG(bytes_ok(t_bytes), "timestep width must be 4 or 8 bytes");
+  D3PM_CHECK_ARG(ld >= tb->K, "row stride %ld smaller than K=%d", ld, tb->K);
+  if (!tb->structured) {
+    set_error("gradient of q_posterior_logits is implemented for column-structured (uniform / absorbing) tables");
+    return D3PM_EUNSUPPORTED;
+  }
+  if (B == 0 || npos == 0) return D3PM_OK;
+  D3PM_CHECK_ARG(x_start_logits && t && grad_out && grad_logits, "null pointer");
+  const bool vec = aligned16(x_start_logits) && aligned16(grad_out) && aligned16(grad_logits) && ld == tb->K;
+  return dispatch_layout(tb->K, vec, [&](auto lay) {
+    using L = decltype(lay);
+    ImgArgs a = make_args(tb, nullptr, 8, nullptr, 8, t, t_bytes, B, npos, L::G);
+    hipLaunchKernelGGL(k_posterior_logits_backward<L>, dim3(B * a.chunks), dim3(BLOCK), 0, (hipStream_t)stream, a,
+                       x_start_logits, ld, grad_out, grad_logits);
+    D3PM_LAUNCH_CHECK("k_posterior_logits_backward");
     return D3PM_OK;
   });
 }

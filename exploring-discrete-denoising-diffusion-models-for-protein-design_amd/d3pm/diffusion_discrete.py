@@ -119,6 +119,8 @@ class _FusedLoss(torch.autograd.Function):
                                    ptr(t), tok_bytes(t), B, npos, loss_type, float(lam), float(baked), None,
                                    None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), ws_bytes, stream_ptr()))
         ctx.dl, ctx.baked, ctx.shape, ctx.dtype = dl, float(baked), logits.shape, logits.dtype
+        if want_grad:       # kept for a second backward (retain_graph): the kernel is run again with the new upstream
+            ctx.again = (lg, x0, x_t, t, tables, loss_type, float(lam))
         return loss
 
     @staticmethod
@@ -126,16 +128,70 @@ class _FusedLoss(torch.autograd.Function):
         dl = ctx.dl
         if dl is None:
             return (None,) * 8
-        if getattr(ctx, "spent", False):
-            raise RuntimeError("the fused D3PM loss keeps one gradient buffer: backward twice is not supported")
-        ctx.spent = True
         g = g.contiguous().float()
         B = g.shape[0]
-        check(lib.d3pm_scale_rows(ptr(dl), ptr(g), ctx.baked, B, dl.numel() // max(B, 1), stream_ptr()))
+        if getattr(ctx, "spent", False):
+            # the first backward gave its buffer away (rescaled in place): recompute the gradient with this
+            # upstream gradient passed to the kernel
+            lg, x0, x_t, t, tables, loss_type, lam = ctx.again
+            npos = x0.numel() // max(B, 1)
+            dl = torch.empty_like(lg)
+            ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tables.K)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=lg.device)
+            with torch.cuda.device(lg.device):
+                check(lib.d3pm_hybrid_loss(tables.desc(), ptr(lg), tables.K, ptr(x0), tok_bytes(x0), ptr(x_t),
+                                           tok_bytes(x_t), ptr(t), tok_bytes(t), B, npos, loss_type, lam, 1.0, ptr(g),
+                                           None, None, None, ptr(dl), None, None, 0, ptr(ws), ws_bytes, stream_ptr()))
+        else:
+            ctx.spent = True
+            check(lib.d3pm_scale_rows(ptr(dl), ptr(g), ctx.baked, B, dl.numel() // max(B, 1), stream_ptr()))
         out = dl.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)
         return out, None, None, None, None, None, None, None
+
+
+class _PosteriorFromLogits(torch.autograd.Function):
+    """q_posterior_logits(x_start_logits=True) with its gradient to the x_start logits (what autograd derives
+    from d3pm/diffusion_discrete.py:320-336 in the reference).  Column-structured tables: one kernel each way;
+    dense tables: the backward contracts with the float32 table copies through a library GEMM."""
+
+    @staticmethod
+    def forward(ctx, xs, x_t, t, tables):
+        K = tables.K
+        B = x_t.shape[0]
+        npos = x_t.numel() // max(B, 1)
+        lg = xs.contiguous()
+        if lg.dtype != torch.float32:
+            lg = lg.float()
+        out = torch.empty(x_t.shape + (K,), dtype=torch.float32, device=x_t.device)
+        with torch.cuda.device(x_t.device):
+            check(lib.d3pm_q_posterior_logits(tables.desc(), ptr(lg), 1, K, 8, ptr(x_t), tok_bytes(x_t), ptr(t),
+                                              tok_bytes(t), B, npos, ptr(out), stream_ptr()))
+        ctx.save_for_backward(lg, t)
+        ctx.tables, ctx.dims, ctx.dtype = tables, (B, npos), xs.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, t = ctx.saved_tensors
+        tables, (B, npos) = ctx.tables, ctx.dims
+        K = tables.K
+        g = g.contiguous().float()
+        if tables.structured:
+            gz = torch.empty_like(lg)
+            with torch.cuda.device(lg.device):
+                check(lib.d3pm_q_posterior_logits_backward(tables.desc(), ptr(lg), K, ptr(t), tok_bytes(t), B, npos,
+                                                           ptr(g), ptr(gz), stream_ptr()))
+        else:
+            tl = t.long()
+            pi = torch.softmax(lg.reshape(B, npos, K), dim=-1)
+            Qm = tables.qbar[(tl - 1).clamp(min=0)]                           # [B,K,K] float32 (row t-1; unused at t = 0)
+            gf2 = g.reshape(B, npos, K) / (torch.bmm(pi, Qm) + tables.eps)
+            gpi = torch.bmm(gf2, Qm.transpose(1, 2))
+            gz = pi * (gpi - (pi * gpi).sum(-1, keepdim=True))
+            gz = torch.where((tl == 0)[:, None, None], g.reshape(B, npos, K), gz).reshape(lg.shape)
+        return (gz if gz.dtype == ctx.dtype else gz.to(ctx.dtype)), None, None, None
 
 
 class _Handoff(torch.autograd.Function):
@@ -297,6 +353,8 @@ class DiscreteDiffusion:
         xt, t = _as_tokens(x_t), _as_tokens(t)
         _lib.require_device(xs, xt)
         tb = self.tables()
+        if x_start_logits and torch.is_grad_enabled() and x_start.requires_grad:
+            return _PosteriorFromLogits.apply(x_start, xt, t, tb)
         B, npos = self._dims(xt)
         out = torch.empty(xt.shape + (K,), dtype=torch.float32, device=xt.device)
         with torch.cuda.device(xt.device):
@@ -320,8 +378,7 @@ class DiscreteDiffusion:
         pred = self._denoiser_logits(model_fn, x, t)
         if self.model_prediction != "x_start":
             raise NotImplementedError(self.model_prediction)
-        with torch.no_grad():
-            ml = self.q_posterior_logits(pred.detach(), x, t, x_start_logits=True)
+        ml = self.q_posterior_logits(pred, x, t, x_start_logits=True)      # differentiable with respect to pred
         assert ml.shape == pred.shape == x.shape + (self.num_pixel_vals,)
         return ml, pred
 

@@ -55,6 +55,8 @@ class _LVB(torch.autograd.Function):
         check(lib.d3pm_lvb_loss(tables.desc(), ptr(pr), ld, ptr(x0), ptr(x_t), ptr(t), ptr(q), B, npos, int(tmax),
                                 int(msa), float(baked), ptr(per), ptr(dp), ptr(ws), ws_bytes, stream_ptr()))
         ctx.dp, ctx.baked, ctx.shape, ctx.dtype = dp, float(np.float32(baked)), pred.shape, pred.dtype
+        if want_grad:       # kept for a second backward (retain_graph): the kernel is run again
+            ctx.again = (pr, x0, x_t, t, q, tables, int(tmax), int(msa))
         return per
 
     @staticmethod
@@ -62,12 +64,22 @@ class _LVB(torch.autograd.Function):
         dp = ctx.dp
         if dp is None:
             return (None,) * 9
-        if getattr(ctx, "spent", False):
-            raise RuntimeError("the fused LVB loss keeps one gradient buffer: backward twice is not supported")
-        ctx.spent = True
         g = g.contiguous().float()
         B = g.shape[0]
-        check(lib.d3pm_scale_rows(ptr(dp), ptr(g), ctx.baked, B, dp.numel() // max(B, 1), stream_ptr()))
+        baked = ctx.baked
+        if getattr(ctx, "spent", False):
+            # the first backward gave its buffer away (rescaled in place): recompute with unit scale
+            pr, x0, x_t, t, q, tables, tmax, msa = ctx.again
+            npos = x0.numel() // max(B, 1)
+            dp, baked = torch.empty_like(pr), 1.0
+            per = torch.empty(B, dtype=torch.float64, device=pr.device)
+            ws_bytes = lib.d3pm_lvb_loss_workspace(B, npos, tables.K)
+            ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=pr.device)
+            with torch.cuda.device(pr.device):
+                check(lib.d3pm_lvb_loss(tables.desc(), ptr(pr), pr.shape[-1], ptr(x0), ptr(x_t), ptr(t), ptr(q), B, npos,
+                                        tmax, msa, 1.0, ptr(per), ptr(dp), ptr(ws), ws_bytes, stream_ptr()))
+        ctx.spent = True
+        check(lib.d3pm_scale_rows(ptr(dp), ptr(g), baked, B, dp.numel() // max(B, 1), stream_ptr()))
         out = dp.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)

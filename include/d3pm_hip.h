@@ -151,6 +151,17 @@ int d3pm_q_posterior_logits(const d3pm_tables_f32* tb, const void* x_start, int 
                             int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
                             int B, long npos, float* out, void* stream);
 
+/* Gradient of d3pm_q_posterior_logits(x_start_is_logits != 0) with respect to
+ * the x_start logits: what autograd derives in the reference from
+ * q_posterior_logits (:320-336) / p_logits (:362-366) when a caller builds a
+ * loss of its own on those logits.  grad_out float32 [B,npos,K] (gradient at
+ * the posterior logits), grad_logits float32 [B,npos,ld].  Column-structured
+ * tables only (D3PM_EUNSUPPORTED otherwise: the facade contracts dense tables
+ * with a library GEMM instead). */
+int d3pm_q_posterior_logits_backward(const d3pm_tables_f32* tb, const float* x_start_logits, long ld,
+                                     const void* t, int t_bytes, int B, long npos, const float* grad_out,
+                                     float* grad_logits, void* stream);
+
 /* Workspace (bytes) d3pm_hybrid_loss needs for B x npos x K. */
 size_t d3pm_hybrid_loss_workspace(int B, long npos, int K);
 

@@ -188,6 +188,59 @@ def test_seeded_against_oracle_odd_shapes(pkg):
             close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
 
 
+@pytest.mark.parametrize("kind,bits", [("uniform", 5), ("absorbing", 4), ("gaussian", 4), ("uniform", 3)])
+def test_p_logits_gradient_against_oracle(pkg, kind, bits):
+    """p_logits / q_posterior_logits(x_start_logits=True) carry autograd as in the reference (:312-381): a loss a
+    caller builds on the posterior logits reaches the denoiser output.  Structured tables through the backward
+    kernel, dense ones through the library contraction; t = 0 rows pass the gradient through."""
+    K, T, B, shape = 2 ** bits, 12, 4, (5, 3)
+    betas = pkg.generate_betas(0.02, 0.5, T, "linear")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.01, device=DEV)
+    p = im.build_process(betas, kind, bits, None, hybrid_coeff=0.01)
+    gen = torch.Generator().manual_seed(bits)
+    x_t = torch.randint(0, K, (B,) + shape + (1,), generator=gen)
+    t = torch.tensor([0, 1, 5, T - 1])
+    z = torch.randn((B,) + shape + (1, K), generator=gen)
+    W = torch.randn(z.shape, generator=gen)
+    z_ref = z.clone().requires_grad_(True)
+    ml_ref = im.model_logits(p, z_ref, x_t, t)[0]
+    (ml_ref * W).sum().backward()
+    z_dev = z.to(DEV).requires_grad_(True)
+    ml, px0 = d.p_logits(lambda x, tt: z_dev * 1.0, x=x_t.to(DEV), t=t.to(DEV))
+    close(ml, ml_ref.detach().numpy(), atol=1e-5, what="p_logits")
+    (ml * W.to(DEV)).sum().backward()
+    ref = z_ref.grad.numpy()
+    close(z_dev.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"d p_logits / d logits {kind}")
+    post = d.q_posterior_logits(z_dev, x_t.to(DEV), t.to(DEV), x_start_logits=True)
+    assert post.requires_grad and torch.equal(post.detach(), ml.detach())
+    with torch.no_grad():
+        assert not d.q_posterior_logits(z_dev, x_t.to(DEV), t.to(DEV), x_start_logits=True).requires_grad
+
+
+def test_backward_twice_with_retain_graph(pkg):
+    """The loss nodes hand their gradient buffer to the first backward; a second backward through a retained graph
+    (the reference supports it) recomputes, with the new upstream gradient."""
+    K, T, B, npos = 32, 20, 6, 50
+    betas = pkg.generate_betas(0.0, 0.0, T, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=5, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                              hybrid_coeff=0.01, device=DEV)
+    x0 = torch.randint(0, K, (B, npos), device=DEV)
+    t = torch.randint(0, T, (B,), device=DEV)
+    z = torch.randn(B, npos, K, device=DEV, requires_grad=True)
+    noise = torch.rand(B, npos, K, device=DEV)
+    losses = d.training_losses(lambda x, tt: z, x_start=x0, t=t, noise=noise)
+    w1, w2 = torch.rand(B, device=DEV), torch.rand(B, device=DEV)
+    g1, = torch.autograd.grad((losses * w1).sum(), z, retain_graph=True)
+    g1 = g1.clone()
+    g2, = torch.autograd.grad((losses * w2).sum(), z, retain_graph=True)
+    ones, = torch.autograd.grad(losses.sum(), z)
+    close(g1, (ones * w1[:, None, None]).cpu().numpy(), rtol=1e-5, atol=1e-9, what="first backward")
+    close(g2, (ones * w2[:, None, None]).cpu().numpy(), rtol=1e-5, atol=1e-9, what="second backward")
+
+
 def _oracle_process(betas, kind, K, lam):
     """`im.build_process` for any K (the reference only builds K = 2 ** num_bits)."""
     one = im._onestep_uniform if kind == "uniform" else im._onestep_absorbing

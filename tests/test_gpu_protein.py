@@ -95,6 +95,39 @@ def test_lvb_loss_golden(pkg, tables500, n_tok):
     np.testing.assert_allclose(pred2.grad.cpu().numpy(), 7.5 * ref, rtol=1e-4, atol=7.5e-5 * np.abs(ref).max())
 
 
+def test_lvb_backward_twice_and_msa_collater_input(pkg, tables500):
+    """(1) A second backward through a retained graph recomputes the gradient (the reference supports it).
+    (2) CollaterMSA's default output -- q_x appended twice, [2B, D, L, K] -- goes straight into D3PMLVBLossMSA, as
+    in the reference, which only reads q[i] for i < B; a t == tmax row makes the loss read it."""
+    from d3pm_amd.protein_generation.dataset import CollaterMSA
+    tok, Qb, Qt = tables500
+    g = golden("protein_lvb_blat")
+    x0, x_t, ts, q = T_(g["x0"]), T_(g["x_t"]), T_(g["timestep"]), T_(g["q"])
+    pred = T_(g["pred24"]).requires_grad_(True)
+    per = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, evaluation=True)(tok.one_hot(x_t), q, pred, x0, tok.one_hot(x0), ts, Qt, Qb)
+    w1, w2 = torch.rand(8, device=DEV, dtype=torch.float64), torch.rand(8, device=DEV, dtype=torch.float64)
+    g1, = torch.autograd.grad((per * w1).sum(), pred, retain_graph=True)
+    g1 = g1.clone()
+    g2, = torch.autograd.grad((per * w2).sum(), pred, retain_graph=True)
+    ones, = torch.autograd.grad(per.sum(), pred)
+    for got, w in ((g1, w1), (g2, w2)):
+        want = (ones * w.float()[:, None, None]).cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-7 * np.abs(want).max())
+    # collater -> MSA loss
+    msas = [["ACDEFGHIKL", "ACDEFGHIKV", "MCDEFGH-KL"], ["LKIHGFEDCA", "LKIHGFEDCM", "LKIHG-EDCA"]]
+    coll = CollaterMSA(tokenizer=tok, num_steps=500, Q=Qt, Q_bar=Qb, device=DEV)
+    src, src_oh, tsm, tgt, tgt_oh, Qc, Qbc, q_x = coll(msas)
+    assert q_x.shape[0] == 2 * len(msas)
+    tsm = tsm.clone()
+    tsm[0] = 500                                              # the branch that reads q
+    pm = torch.randn(tuple(tgt.shape) + (24,), device=DEV, requires_grad=True)
+    loss = pkg.D3PMLVBLossMSA(tmax=500, tokenizer=tok)(src_oh, q_x, pm, tgt, tgt_oh, tsm, Qc, Qbc)
+    want = pkg.D3PMLVBLossMSA(tmax=500, tokenizer=tok)(src_oh, q_x[:len(msas)], pm, tgt, tgt_oh, tsm, Qc, Qbc)
+    assert torch.isfinite(loss) and torch.equal(loss, want)
+    loss.backward()
+    assert torch.isfinite(pm.grad).all()
+
+
 def test_lvb_loss_msa_golden(pkg, tables500):
     tok, Qb, Qt = tables500
     g = golden("protein_lvb_msa")
