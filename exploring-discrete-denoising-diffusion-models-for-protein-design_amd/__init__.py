@@ -8,6 +8,7 @@ ABI of ``libd3pm_hip.so`` (``include/d3pm_hip.h``); importing the package
 without that library raises.
 """
 from . import _lib  # noqa: F401  (loads libd3pm_hip.so or raises)
+from . import _ops  # noqa: F401  (registers torch.ops.d3pm_mi355x or raises)
 from . import tables  # noqa: F401
 from . import graphs  # noqa: F401
 from . import d3pm  # noqa: F401

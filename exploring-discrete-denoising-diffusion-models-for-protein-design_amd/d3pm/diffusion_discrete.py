@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .._lib import lib, check, ptr, stream_ptr, tok_bytes
+from .._ops import ops, i64
 from ..tables import ImageTables
 from . import utils
 
@@ -111,13 +112,10 @@ class _FusedLoss(torch.autograd.Function):
         if lg.dtype != torch.float32:
             lg = lg.float()
         want_grad = ctx.needs_input_grad[0]
-        loss = torch.empty(B, dtype=torch.float32, device=lg.device)
-        dl = torch.empty_like(lg) if want_grad else None
-        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, K)
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=lg.device)
-        check(lib.d3pm_hybrid_loss(tables.desc(), ptr(lg), K, ptr(x0), tok_bytes(x0), ptr(x_t), tok_bytes(x_t),
-                                   ptr(t), tok_bytes(t), B, npos, loss_type, float(lam), float(baked), None,
-                                   None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), ws_bytes, stream_ptr()))
+        loss, _, _, dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, float(lam), float(baked), None,
+                                         want_grad)
+        if not want_grad:
+            dl = None
         ctx.dl, ctx.baked, ctx.shape, ctx.dtype = dl, float(baked), logits.shape, logits.dtype
         if want_grad:       # kept for a second backward (retain_graph): the kernel is run again with the new upstream
             ctx.again = (lg, x0, x_t, t, tables, loss_type, float(lam))
@@ -134,17 +132,12 @@ class _FusedLoss(torch.autograd.Function):
             # the first backward gave its buffer away (rescaled in place): recompute the gradient with this
             # upstream gradient passed to the kernel
             lg, x0, x_t, t, tables, loss_type, lam = ctx.again
-            npos = x0.numel() // max(B, 1)
-            dl = torch.empty_like(lg)
-            ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tables.K)
-            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=lg.device)
             with torch.cuda.device(lg.device):
-                check(lib.d3pm_hybrid_loss(tables.desc(), ptr(lg), tables.K, ptr(x0), tok_bytes(x0), ptr(x_t),
-                                           tok_bytes(x_t), ptr(t), tok_bytes(t), B, npos, loss_type, lam, 1.0, ptr(g),
-                                           None, None, None, ptr(dl), None, None, 0, ptr(ws), ws_bytes, stream_ptr()))
+                dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, lam, 1.0, g, True)[3]
         else:
             ctx.spent = True
-            check(lib.d3pm_scale_rows(ptr(dl), ptr(g), ctx.baked, B, dl.numel() // max(B, 1), stream_ptr()))
+            with torch.cuda.device(dl.device):
+                ops.scale_rows_(dl, g, ctx.baked)
         out = dl.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)
@@ -164,10 +157,8 @@ class _PosteriorFromLogits(torch.autograd.Function):
         lg = xs.contiguous()
         if lg.dtype != torch.float32:
             lg = lg.float()
-        out = torch.empty(x_t.shape + (K,), dtype=torch.float32, device=x_t.device)
         with torch.cuda.device(x_t.device):
-            check(lib.d3pm_q_posterior_logits(tables.desc(), ptr(lg), 1, K, 8, ptr(x_t), tok_bytes(x_t), ptr(t),
-                                              tok_bytes(t), B, npos, ptr(out), stream_ptr()))
+            out = ops.q_posterior_logits(*tables.op_args(), lg, True, x_t, t)
         ctx.save_for_backward(lg, t)
         ctx.tables, ctx.dims, ctx.dtype = tables, (B, npos), xs.dtype
         return out
@@ -179,10 +170,8 @@ class _PosteriorFromLogits(torch.autograd.Function):
         K = tables.K
         g = g.contiguous().float()
         if tables.structured:
-            gz = torch.empty_like(lg)
             with torch.cuda.device(lg.device):
-                check(lib.d3pm_q_posterior_logits_backward(tables.desc(), ptr(lg), K, ptr(t), tok_bytes(t), B, npos,
-                                                           ptr(g), ptr(gz), stream_ptr()))
+                gz = ops.q_posterior_logits_backward(*tables.op_args(), lg, t, g)
         else:
             tl = t.long()
             pi = torch.softmax(lg.reshape(B, npos, K), dim=-1)
@@ -290,13 +279,10 @@ class DiscreteDiffusion:
         """q(x_t | x_start) as float32 [..., K] (:250-263)."""
         x = _as_tokens(x_start)
         tb = self.tables()
-        B, npos = self._dims(x)
-        out = torch.empty(x.shape + (tb.K,), dtype=torch.float32, device=x.device)
+        _lib.require_device(x)
         t = _as_tokens(t)
         with torch.cuda.device(x.device):
-            check(lib.d3pm_q_probs(tb.desc(), ptr(x), tok_bytes(x), ptr(t), tok_bytes(t), B, npos, ptr(out),
-                                   stream_ptr()))
-        return out
+            return ops.q_probs(*tb.op_args(), x, t)
 
     def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform", rng=None):
         """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64.
@@ -323,11 +309,8 @@ class DiscreteDiffusion:
             assert noise.shape == x.shape + (tb.K,), noise.shape
             kind = _lib.NOISE[noise_kind]
             noise = noise.contiguous().float()
-        out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
         with torch.cuda.device(x.device):
-            check(lib.d3pm_q_sample(tb.desc(), ptr(x), tok_bytes(x), ptr(t), tok_bytes(t), B, npos, ptr(noise), kind,
-                                    seed, off, ptr(off_dev), ptr(out), stream_ptr()))
-        return out
+            return ops.q_sample(*tb.op_args(), x, t, noise, kind, i64(seed), i64(off), off_dev)
 
     # ------------------------------------------------------------------ posterior
     def _get_logits_from_logistic_pars(self, loc, log_scale):
@@ -355,13 +338,8 @@ class DiscreteDiffusion:
         tb = self.tables()
         if x_start_logits and torch.is_grad_enabled() and x_start.requires_grad:
             return _PosteriorFromLogits.apply(x_start, xt, t, tb)
-        B, npos = self._dims(xt)
-        out = torch.empty(xt.shape + (K,), dtype=torch.float32, device=xt.device)
         with torch.cuda.device(xt.device):
-            check(lib.d3pm_q_posterior_logits(tb.desc(), ptr(xs), int(bool(x_start_logits)), K,
-                                              8 if x_start_logits else tok_bytes(xs), ptr(xt), tok_bytes(xt),
-                                              ptr(t), tok_bytes(t), B, npos, ptr(out), stream_ptr()))
-        return out
+            return ops.q_posterior_logits(*tb.op_args(), xs.detach(), bool(x_start_logits), xt, t)
 
     def _denoiser_logits(self, model_fn, x, t):
         out = model_fn(x, t)
@@ -415,12 +393,10 @@ class DiscreteDiffusion:
             assert noise.shape == lg.shape, noise.shape
             kind = _lib.NOISE[noise_kind]
             noise = noise.contiguous().float()
-        sample = torch.empty(xt.shape, dtype=torch.int64, device=xt.device)
-        probs = torch.empty_like(lg) if want_probs else None
         with torch.cuda.device(xt.device):
-            check(lib.d3pm_p_sample(tb.desc(), ptr(lg), K, ptr(xt), tok_bytes(xt), ptr(t), tok_bytes(t), B, npos,
-                                    ptr(noise), kind, seed, off, ptr(off_dev), ptr(sample), ptr(probs), stream_ptr()))
-        return sample, probs
+            sample, probs = ops.p_sample(*tb.op_args(), lg, xt, t, noise, kind, i64(seed), i64(off), off_dev,
+                                         bool(want_probs))
+        return sample, (probs if want_probs else None)
 
     @torch.no_grad()
     def p_sample_loop(self, model_fn, *, shape, num_timesteps=None, return_x_init=False, return_im_steps=False,
@@ -486,14 +462,8 @@ class DiscreteDiffusion:
         _lib.require_device(x)
         tb = self.tables()
         B, npos = self._dims(x)
-        out = torch.empty(B, dtype=torch.float32, device=x.device)
-        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            check(lib.d3pm_prior_bpd(tb.desc(), ptr(x), tok_bytes(x), B, npos,
-                                     int(self.transition_mat_type == "absorbing"), ptr(out), ptr(ws), ws_bytes,
-                                     stream_ptr()))
-        return out
+            return ops.prior_bpd(*tb.op_args(), x, self.transition_mat_type == "absorbing")
 
     def cross_entropy_start(self, x_start, pred_x_start_logits):
         """Cross entropy of x_start under the predicted logits, bits/dim (:527-542)."""

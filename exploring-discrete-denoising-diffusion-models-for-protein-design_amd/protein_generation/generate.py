@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
-from .._lib import lib, check, ptr, stream_ptr
+from .._ops import ops, i64
 from ..tables import protein_tables
 from ..sharding import shard_range, equal_sub_batches, gather_token_shards  # noqa: F401  (re-exported)
 
@@ -40,12 +40,9 @@ def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, ex
         seed, off, counter = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]), rng[2]
     else:
         seed, off = _philox_ticket(x_t.device)
-    out = torch.empty_like(x_t)
     with torch.cuda.device(x_t.device):
-        check(lib.d3pm_lvb_reverse_step(tables.desc(), ptr(pr), pr.shape[-1], ptr(x_t), ptr(t), B, npos, ptr(noise),
-                                        seed, off, ptr(counter), float(last_class_div), int(exclude_last_prefix),
-                                        ptr(out), stream_ptr()))
-    return out
+        return ops.lvb_reverse_step(*tables.op_args(), pr, x_t, t, noise, i64(seed), i64(off), counter,
+                                    float(last_class_div), int(exclude_last_prefix))
 
 
 def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, device, batch_size=3, x_init=None, noise_fn=None):

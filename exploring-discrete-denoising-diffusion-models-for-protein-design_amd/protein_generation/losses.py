@@ -14,7 +14,7 @@ import torch
 from torch.nn import KLDivLoss
 
 from .. import _lib
-from .._lib import lib, check, ptr, stream_ptr
+from .._ops import ops
 from ..tables import protein_tables
 from .constants import MSA_AAS
 from .utils import Tokenizer
@@ -48,12 +48,9 @@ class _LVB(torch.autograd.Function):
             pr = pr.float()
         ld = pr.shape[-1]
         want_grad = ctx.needs_input_grad[0]
-        per = torch.empty(B, dtype=torch.float64, device=pr.device)
-        dp = torch.empty_like(pr) if want_grad else None
-        ws_bytes = lib.d3pm_lvb_loss_workspace(B, npos, tables.K)
-        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=pr.device)
-        check(lib.d3pm_lvb_loss(tables.desc(), ptr(pr), ld, ptr(x0), ptr(x_t), ptr(t), ptr(q), B, npos, int(tmax),
-                                int(msa), float(baked), ptr(per), ptr(dp), ptr(ws), ws_bytes, stream_ptr()))
+        per, dp = ops.lvb_loss(*tables.op_args(), pr, x0, x_t, t, q, int(tmax), int(msa), float(baked), want_grad)
+        if not want_grad:
+            dp = None
         ctx.dp, ctx.baked, ctx.shape, ctx.dtype = dp, float(np.float32(baked)), pred.shape, pred.dtype
         if want_grad:       # kept for a second backward (retain_graph): the kernel is run again
             ctx.again = (pr, x0, x_t, t, q, tables, int(tmax), int(msa))
@@ -70,16 +67,12 @@ class _LVB(torch.autograd.Function):
         if getattr(ctx, "spent", False):
             # the first backward gave its buffer away (rescaled in place): recompute with unit scale
             pr, x0, x_t, t, q, tables, tmax, msa = ctx.again
-            npos = x0.numel() // max(B, 1)
-            dp, baked = torch.empty_like(pr), 1.0
-            per = torch.empty(B, dtype=torch.float64, device=pr.device)
-            ws_bytes = lib.d3pm_lvb_loss_workspace(B, npos, tables.K)
-            ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=pr.device)
+            baked = 1.0
             with torch.cuda.device(pr.device):
-                check(lib.d3pm_lvb_loss(tables.desc(), ptr(pr), pr.shape[-1], ptr(x0), ptr(x_t), ptr(t), ptr(q), B, npos,
-                                        tmax, msa, 1.0, ptr(per), ptr(dp), ptr(ws), ws_bytes, stream_ptr()))
+                dp = ops.lvb_loss(*tables.op_args(), pr, x0, x_t, t, q, tmax, msa, 1.0, True)[1]
         ctx.spent = True
-        check(lib.d3pm_scale_rows(ptr(dp), ptr(g), baked, B, dp.numel() // max(B, 1), stream_ptr()))
+        with torch.cuda.device(dp.device):
+            ops.scale_rows_(dp, g, baked)
         out = dp.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)

@@ -74,12 +74,10 @@ def corrupt_batch(tables: ProteinTables, x0, t, noise=None, want_probs=False):
     else:
         noise = noise.to(device=x0.device, dtype=torch.float64).contiguous()
         assert noise.shape == x0.shape + (tables.K,), noise.shape
-    x_t = torch.empty_like(x0)
-    probs = torch.empty(x0.shape + (tables.K,), dtype=torch.float64, device=x0.device) if want_probs else None
+    from .._ops import ops, i64
     with torch.cuda.device(x0.device):
-        check(lib.d3pm_corrupt(tables.desc(), ptr(x0), ptr(t), B, npos, ptr(noise), seed, off, ptr(x_t), ptr(probs),
-                               stream_ptr()))
-    return x_t, probs
+        x_t, probs = ops.corrupt(*tables.op_args(), x0, t, noise, i64(seed), i64(off), bool(want_probs))
+    return x_t, (probs if want_probs else None)
 
 
 class Tokenizer(object):

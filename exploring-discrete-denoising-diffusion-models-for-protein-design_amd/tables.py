@@ -71,6 +71,15 @@ class ImageTables:
     def desc(self):
         return C.byref(self._desc)
 
+    def op_args(self):
+        """Leading arguments of the torch.ops.d3pm_mi355x image-style operators."""
+        e = getattr(self, "_empty", None)
+        if e is None:
+            e = self._empty = torch.empty(0, dtype=torch.float32, device=self.device)
+        return ([self.qbar_digest, self.qone_digest, e if self.qbar is None else self.qbar,
+                 e if self.qoneT is None else self.qoneT, e if self.qbarT is None else self.qbarT],
+                self.K, self.T, bool(self.structured), self.eps)
+
 
 class ProteinTables:
     """float64 column-structured digests of (Q_t, Qbar_t) for the protein-style
@@ -105,6 +114,10 @@ class ProteinTables:
 
     def desc(self):
         return C.byref(self._desc)
+
+    def op_args(self):
+        """Leading arguments of the torch.ops.d3pm_mi355x protein-style operators."""
+        return (self.qbar_digest, self.qone_digest, self.K, self.T)
 
 
 _protein_cache: Dict[tuple, ProteinTables] = {}

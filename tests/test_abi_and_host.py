@@ -33,7 +33,21 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, n), f"{n} declared in include/d3pm_hip.h but not exported"
     # and the binding lists exactly the header's functions
     assert sorted(pkg._lib.SIGNATURES) == names
-    assert pkg._lib.lib.d3pm_abi_version() == 6
+    assert pkg._lib.lib.d3pm_abi_version() == 7
+
+
+def test_torch_ops_registered(pkg):
+    """The PyTorch-extension form of the boundary: libd3pm_torch_ops.so loads and registers every operator of
+    torch.ops.d3pm_mi355x (no compute calls here), and the operators refuse CPU tensors."""
+    for name in pkg._ops.OP_NAMES:
+        assert hasattr(torch.ops.d3pm_mi355x, name), name
+    schema = torch.ops.d3pm_mi355x.hybrid_loss.default._schema
+    assert [a.name for a in schema.arguments][:5] == ["tables", "K", "T", "structured", "eps"]
+    assert len(schema.returns) == 4
+    x = torch.zeros(2, 3, dtype=torch.int64)
+    e = torch.empty(0)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.d3pm_mi355x.q_probs([e, e, e, e, e], 4, 2, True, 1e-6, x, torch.zeros(2, dtype=torch.int64))
 
 
 def test_struct_layout_matches_header(pkg):
