@@ -209,6 +209,12 @@ def worker(args):
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
+    t_start = time.perf_counter()
+
+    def progress(what):
+        """One stderr line per section when D3PM_BENCH_PROGRESS is set (a run under a profiler shows where it is)."""
+        if os.environ.get("D3PM_BENCH_PROGRESS") and rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {what}", file=sys.stderr, flush=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
@@ -317,7 +323,8 @@ def worker(args):
         frozen_fn = lambda x, tt: frozen[:x.shape[0]]
         # [path only, with a tiny denoiser] x [distinct sub-batch sizes]
         samplers = [{nb: d3pm_amd.graphs.GraphedReverseSampler(ptab, fn, nb, SEQ_LEN, T_PROT, dev,
-                                                                seed=77 + rank + 1000 * k)
+                                                                seed=77 + rank + 1000 * k,
+                                                                capture=not args.no_graph)
                      for k, nb in enumerate(sorted(set(sub_sizes))) if nb > 0} for fn in (frozen_fn, tiny)]
     torch.cuda.synchronize()
     ranks_seen = 1
@@ -372,10 +379,12 @@ def worker(args):
             el = float(el_.item())
         return el, reps
 
+    progress("timed steps")
     elapsed, reps = timed_steps(run_steps, args.steps, args.warmup)
     n_timed = args.steps * reps
     tokens = B * L * n_timed * world
 
+    progress("single-step and other call shape")
     single_ms = None
     if spg > 1:                     # for the record: one step per graph replay (host-launch-bound)
         for _ in range(20):
@@ -434,9 +443,11 @@ def worker(args):
                                        None, 0, ptr(ws), wsb, sp))
         return event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10)
 
+    progress("fused kernel back to back")
     kern_ms = fused_kernel_ms(d)
     kern_rot_ms = None if args.no_secondary else fused_kernel_ms(d, nsets=10)
 
+    progress("absorbing")
     absorbing = None
     if run_abs is not None:
         for _ in range(3):
@@ -454,6 +465,7 @@ def worker(args):
                                   "frac": a_ach / HBM_PEAK_GBS, "kernel_ms": ak}}
 
     # ---- secondary: reverse sampling
+    progress("reverse sampling")
     reverse = None
     if samplers is not None:
         def run_sampler(smps):
@@ -498,19 +510,21 @@ def worker(args):
         reverse = {"value": done / rev_el, "unit": "seqs/s",
                    "what": f"full T={T_PROT} ({T_PROT - 1} steps) reverse sampling, L={SEQ_LEN}, K={K_PROT}, {N_SEQS} "
                            f"sequences sharded over {world} GPU(s), every rank its contiguous share in sub-batches of "
-                           f"{sorted(set(sub_sizes), reverse=True)} sequences, the loop of each sub-batch replayed as "
-                           "one HIP graph, path only (frozen logits)",
+                           f"{sorted(set(sub_sizes), reverse=True)} sequences, the loop of each sub-batch "
+                           + ("launched step by step" if args.no_graph else "replayed as one HIP graph")
+                           + ", path only (frozen logits)",
                    "sequences": done, "seconds": rev_el,
                    "end_to_end_tiny_denoiser": done_e2e / e2e_el,
                    "roofline": {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_device_noise via "
+                                "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_tpl<22, 22> via "
                                 "d3pm_lvb_reverse_step, back-to-back launches between two HIP events",
                                 "kernel_ms": rk_ms, "algorithmic_bytes_per_token": rbytes,
                                 "tokens_per_launch": nb * SEQ_LEN,
-                                "traffic": measured_traffic("k_lvb_reverse_device_noise")}}
+                                "traffic": measured_traffic("k_lvb_reverse_tpl")}}
 
     # ---- secondary: the image configuration (B=128, 32x32x1, K=256, T=1000, Gaussian Q): dense contraction on
     # the matrix cores, fused loss fwd+bwd; priced against the dense float32 MFMA peak
+    progress("image K=256")
     dense = None
     if rank == 0 and not args.no_secondary:
         KI, TI, BI, LI = 256, 1000, 128, 1024
@@ -542,6 +556,7 @@ def worker(args):
 
     # ---- secondary: the protein-style training loss (D3PMLVBLoss forward + gradient) and the batched forward
     # corruption of the collaters, B=256 L=512 K=22 n_tokens=24, through the C ABI
+    progress("protein LVB")
     lvb = None
     if rank == 0 and not args.no_secondary:
         BP, LP, KP, LDP = 256, 512, 22, 24
@@ -572,18 +587,19 @@ def worker(args):
                            "gradient, B=256 L=512 K=22 n_tokens=24, back-to-back launches",
                "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": l_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss via d3pm_lvb_loss, back-to-back launches "
+                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24> via d3pm_lvb_loss, back-to-back launches "
                             "between two HIP events", "kernel_ms": lk_ms, "algorithmic_bytes_per_token": lbytes,
-                            "traffic": measured_traffic("k_lvb_loss")}}
+                            "traffic": measured_traffic("k_lvb_loss_tpl")}}
 
+    progress("sections done")
     if rank == 0:
         achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
-        traffic = measured_traffic("k_hybrid_loss", "true>(")
+        traffic = measured_traffic("k_hybrid_loss_tpl<32, true")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": (traffic["source"] + " (a committed rocprofv3 --pmc pass of this command, not "
                                    "measured by this run)") if traffic else None,
-                "kernel": "k_hybrid_loss via d3pm_hybrid_loss, back-to-back launches between two HIP events",
+                "kernel": "k_hybrid_loss_tpl<32, true, 512> via d3pm_hybrid_loss, back-to-back launches between two HIP events",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
                 "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
                         "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "

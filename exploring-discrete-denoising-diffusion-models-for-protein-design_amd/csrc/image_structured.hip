@@ -700,7 +700,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int KC, bool GRAD, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, int stagger) {
   using C = TplCfg<KC>;
   extern __shared__ __align__(16) char tpl_rows[];          // [waves][64][STRIDE]
   __shared__ float red[2 * MAX_WAVES];
@@ -738,27 +738,25 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     }
   };
   unsigned base = pbeg + wave * 64;
-  if (base < p1) issue(base);
+  for (int i = 0; i < wave * stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  // The timestep is requested first: loads retire in issue order, and the digest rows that depend on it should be
+  // on their way while the logits rows arrive.
   int t = load_tok(a.t, b, a.t_bytes);
+  if (base < p1) issue(base);
   t = max(0, min(t, a.tb.T - 1));
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
   // per-class constants of the timestep, wave-uniform: off_j + eps of Qbar_{t-1} by class, their sum, diag - off
+  // (requested here, used after the first rows' softmax: the timestep -> digest chain is the longest latency of
+  // the kernel's start, and that softmax does not need it)
   float boe[KC];
   float bdo = 0, sum_boe = 0;
-  if (need_post) {
-    const float vd = lane < KC ? dg(a.tb.qbar_digest, t - 1, 0, KC)[lane] : 0.0f;
-    const float vo = lane < KC ? dg(a.tb.qbar_digest, t - 1, 1, KC)[lane] : 0.0f;
-    const float vboe = vo + eps;
-    if (lane < KC) {
-      s_tab[wave][0][lane] = dg(a.tb.qone_digest, t, 0, KC)[lane] + eps;
-      s_tab[wave][1][lane] = dg(a.tb.qone_digest, t, 1, KC)[lane] + eps;
-      s_tab[wave][2][lane] = vboe;
-    }
-    bdo = lane_bcast(vd - vo, 0);
-    sum_boe = wave_sum(lane < KC ? vboe : 0.0f);
-#pragma unroll
-    for (int j = 0; j < KC; ++j) boe[j] = lane_bcast(vboe, j);
+  float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
+  if (need_post && lane < KC) {
+    vd = dg(a.tb.qbar_digest, t - 1, 0, KC)[lane];
+    vo = dg(a.tb.qbar_digest, t - 1, 1, KC)[lane];
+    v_ad = dg(a.tb.qone_digest, t, 0, KC)[lane];
+    v_ao = dg(a.tb.qone_digest, t, 1, KC)[lane];
   }
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
@@ -798,6 +796,18 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     }
     if (first) {
       first = false;
+      if (need_post) {
+        const float vboe = vo + eps;
+        if (lane < KC) {
+          s_tab[wave][0][lane] = v_ad + eps;
+          s_tab[wave][1][lane] = v_ao + eps;
+          s_tab[wave][2][lane] = vboe;
+        }
+        bdo = lane_bcast(vd - vo, 0);
+        sum_boe = wave_sum(lane < KC ? vboe : 0.0f);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) boe[j] = lane_bcast(vboe, j);
+      }
       wave_lds_fence();                       // this wave's table copy
       D3PM_TL(4);
     }
@@ -1365,8 +1375,9 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       }
+      static const int stagger = getenv("D3PM_STAGGER") ? atoi(getenv("D3PM_STAGGER")) : 0;
       hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale,
-                         grad_out, o, dlogits);
+                         grad_out, o, dlogits, stagger);
       D3PM_LAUNCH_CHECK("k_hybrid_loss_tpl");
       return D3PM_OK;
     };

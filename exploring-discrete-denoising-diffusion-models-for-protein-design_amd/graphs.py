@@ -122,10 +122,13 @@ class GraphedReverseSampler:
 
     ``model_fn(x [B,L] int64, t [B] int64) -> logits [B,L,n_tokens]`` must be
     capturable.  ``sample(x_init=None)`` returns the static [B,L] result tensor
-    (clone it before the next call); x_T is drawn uniformly unless given."""
+    (clone it before the next call); x_T is drawn uniformly unless given.
+    ``capture=False`` keeps the same object and noise sequence but launches the
+    steps one by one (for runs under a kernel tracer, where single launches are
+    wanted)."""
 
     def __init__(self, tables, model_fn, batch_size: int, seq_len: int, timesteps: int, device, seed: int = 0,
-                 warmup: int = 2):
+                 warmup: int = 2, capture: bool = True):
         from .protein_generation.generate import reverse_step
         self.tables, self.K = tables, tables.K
         dev = torch.device(device)
@@ -149,9 +152,12 @@ class GraphedReverseSampler:
             for _ in range(warmup):
                 reverse_step(tables, model_fn(self.x, tts[0]), self.x, tts[0], rng=(seed, 0, self.counter))
         torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = body()
+        self._body = body
+        self.graph = None
+        if capture:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = body()
 
     def sample(self, x_init=None):
         if x_init is None:
@@ -159,7 +165,11 @@ class GraphedReverseSampler:
         else:
             self.x.copy_(x_init)
         self.counter.add_(self.stride)
-        self.graph.replay()
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            with torch.no_grad():
+                self.out = self._body()
         return self.out
 
 
