@@ -189,6 +189,13 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
 __device__ __forceinline__ int load_tok(const void* p, long idx, int bytes) {
   return bytes == 8 ? (int)((const int64_t*)p)[idx] : ((const int32_t*)p)[idx];
 }
+// Timesteps and class indices address tables, LDS rows and logits columns: values outside their range are brought
+// to the nearest valid one (one v_med3 per value, no fault, no host synchronisation).  Results for such inputs are
+// those of the clamped values.
+__device__ __forceinline__ int clamp_index(int v, int n) { return max(0, min(v, n - 1)); }
+__device__ __forceinline__ int load_index(const void* p, long idx, int bytes, int n) {
+  return clamp_index(load_tok(p, idx, bytes), n);
+}
 
 // ---------------------------------------------------------------- Philox
 struct U4 { uint32_t x, y, z, w; };
@@ -208,6 +215,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id
 }
 // U[0,1) with 24 random bits, like torch.rand for float32.
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }
+// Strictly inside (0, 1): 23 random bits at the centres of 2^-23-wide cells, [2^-24, 1 - 2^-24].  (24 bits plus a
+// half would round to 1.0 for the topmost cell.)
+__device__ __forceinline__ float u01_open(uint32_t r) {
+  return fmaf((float)(r >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f);
+}
 // U[0,1) with 53 random bits.
 __device__ __forceinline__ double u01d_open(uint32_t hi, uint32_t lo) {
   uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;

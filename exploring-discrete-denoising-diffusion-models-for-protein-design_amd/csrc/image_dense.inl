@@ -36,11 +36,11 @@ __global__ __launch_bounds__(BLOCK) void k_dense_q_probs(ImgArgs a, float* __res
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float r[L::V];
     load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, r);
     store_slots<L>(out + n * K, g, K, r);
@@ -56,11 +56,11 @@ __global__ __launch_bounds__(BLOCK) void k_dense_q_sample(ImgArgs a, const float
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float p[L::V], u[L::V];
     load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, p);
     if constexpr (NOISE == D3PM_NOISE_PHILOX) {
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(BLOCK) void k_dense_posterior_tokens(ImgArgs a, flo
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   const float log_one = (float)log((double)(1.0f + eps)), log_zero = (float)log((double)eps);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
-    const int xt = load_tok(a.xt, n, a.xt_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
+    const int xt = load_index(a.xt, n, a.xt_bytes, a.tb.K);
     float r[L::V];
     if (t == 0) {
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_prior(ImgArgs a, int absorbing,
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float p[L::V];
     load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, p);
     float kl = 0;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
   // vector layouts cover exactly K classes: no masked slots
   auto valid = [&](int c) { return L::VEC || c < K; };
-  const int t = __builtin_amdgcn_readfirstlane(load_tok(a.t, b, a.t_bytes));   // one timestep per workgroup
+  const int t = __builtin_amdgcn_readfirstlane(load_index(a.t, b, a.t_bytes, a.tb.T));   // one timestep per workgroup
   const bool need_post = (t > 0) && !(MODE == DENSE_LOSS && e.loss_type == D3PM_LOSS_CE);
   const float* Qm = need_post ? a.tb.qbar + (size_t)(t - 1) * K * K : nullptr;
   const float* QmT = (need_post && GRAD) ? a.tb.qbarT + (size_t)(t - 1) * K * K : nullptr;
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   auto fetch_pass = [&](long tile, int ps) {
     const long n = row_index(tile, ps);
     fetch_row(tile, ps);
-    xtn[ps % NZ] = load_tok(a.xt, n, a.xt_bytes);
-    x0n[ps % NZ] = (MODE == DENSE_LOSS) ? load_tok(a.x0, n, a.x0_bytes) : 0;
+    xtn[ps % NZ] = load_index(a.xt, n, a.xt_bytes, a.tb.K);
+    x0n[ps % NZ] = (MODE == DENSE_LOSS) ? load_index(a.x0, n, a.x0_bytes, a.tb.K) : 0;
   };
   auto fetch_tile = [&](long tile) {
 #pragma unroll
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
 #pragma unroll
             for (int v = 0; v < L::V; ++v) w[v] = valid(L::cls(g, v)) ? (f1n[ps % NZ][v] + eps) * f2e[v] : 0.0f;
             const U4 r = philox4x32_10((uint64_t)n, e.offset, e.seed);
-            const float uu = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+            const float uu = u01_open(r.x);
             pick = group_pick<L::G, L::V>(w, g, uu, tok_xt(ps), [](int gg, int vv) { return L::cls(gg, vv); });
           }
           if (g == 0 && live) e.sample[n] = pick;

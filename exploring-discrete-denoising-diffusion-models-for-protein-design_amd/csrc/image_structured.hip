@@ -46,14 +46,14 @@ __global__ __launch_bounds__(BLOCK) void k_q_probs(ImgArgs a, float* __restrict_
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   float d[L::V], o[L::V];
   load_digest<L>(a.tb.qbar_digest, t, 0, K, g, d);
   load_digest<L>(a.tb.qbar_digest, t, 1, K, g, o);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float r[L::V];
 #pragma unroll
     for (int v = 0; v < L::V; ++v) r[v] = (L::cls(g, v) == x0) ? d[v] : o[v];
@@ -70,14 +70,14 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   float ld_[L::V], lo_[L::V];
   load_digest<L>(a.tb.qbar_digest, t, 2, K, g, ld_);
   load_digest<L>(a.tb.qbar_digest, t, 3, K, g, lo_);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float u[L::V];
     if constexpr (NOISE == D3PM_NOISE_PHILOX) {
       const U4 r = philox4x32_10((uint64_t)n * L::G + g, offset, seed);
@@ -135,13 +135,13 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
   // the first token's load is in flight, and its random words are computed, while the
   // timestep -> digest -> prefix-sum chain runs
   int x0_next = 0;
-  if (pfirst < p1) x0_next = load_tok(a.x0, (long)b * a.npos + pfirst, a.x0_bytes);
+  if (pfirst < p1) x0_next = load_index(a.x0, (long)b * a.npos + pfirst, a.x0_bytes, a.tb.K);
   int t;
   if (t_draw) {
     t = draw_timestep(b, a.tb.T, offset, seed);
     if (chunk == 0 && threadIdx.x == 0) t_draw[b] = t;
   } else {
-    t = load_tok(a.t, b, a.t_bytes);
+    t = load_index(a.t, b, a.t_bytes, a.tb.T);
   }
   const float* dgd_ = dg(a.tb.qbar_digest, t, 0, K);
   const float* dgo_ = dg(a.tb.qbar_digest, t, 1, K);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
     const int x0 = x0_next;
     const U4 r4 = r_next;
     if (pos + blockDim.x < p1) {
-      x0_next = load_tok(a.x0, n + blockDim.x, a.x0_bytes);
+      x0_next = load_index(a.x0, n + blockDim.x, a.x0_bytes, a.tb.K);
       r_next = philox4x32_10((uint64_t)(n + blockDim.x), offset, seed);
     }
     const float extra = dmo[x0];
@@ -246,19 +246,19 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_logits(ImgArgs a, const flo
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   Post<L> P;
   if (t > 0) load_post<L>(a.tb, t, g, P);
   const float log_one = (float)log((double)(1.0f + eps)), log_zero = (float)log((double)eps);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int xt = load_tok(a.xt, n, a.xt_bytes);
+    const int xt = load_index(a.xt, n, a.xt_bytes, a.tb.K);
     float r[L::V];
     float z[L::V];
     int x0 = -1;
     if constexpr (FROM_LOGITS) load_slots<L>(xs_logits + n * ld, g, K, -INFINITY, z);
-    else x0 = load_tok(a.x0, n, a.x0_bytes);
+    else x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     if (t == 0) {
 #pragma unroll
       for (int v = 0; v < L::V; ++v) r[v] = FROM_LOGITS ? z[v] : ((L::cls(g, v) == x0) ? log_one : log_zero);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_logits_backward(ImgArgs a, 
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = max(0, min(load_tok(a.t, b, a.t_bytes), a.tb.T - 1));
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   Post<L> P;
   if (t > 0) load_post<L>(a.tb, t, g, P);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(loss_max_threads<L>()) void k_hybrid_loss(
   if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
   D3PM_TL_DECL;
   D3PM_TL(0);
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
   D3PM_TL_AFTER(1, t);
   float bdo[L::V], boe[L::V], bo[L::V];
@@ -741,9 +741,8 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
   for (int i = 0; i < wave * stagger; ++i) __builtin_amdgcn_s_sleep(1);
   // The timestep is requested first: loads retire in issue order, and the digest rows that depend on it should be
   // on their way while the logits rows arrive.
-  int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   if (base < p1) issue(base);
-  t = max(0, min(t, a.tb.T - 1));
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
   // per-class constants of the timestep, wave-uniform: off_j + eps of Qbar_{t-1} by class, their sum, diag - off
@@ -942,7 +941,7 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = load_tok(a.t, b, a.t_bytes);
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
   Post<L> P;
   if (t > 0) load_post<L>(a.tb, t, g, P);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
@@ -978,7 +977,7 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
     } else if constexpr (NOISE == D3PM_NOISE_PHILOX) {
       // noise drawn on the device: nothing to match bit for bit, so one uniform per token and an inverse CDF over the
       // unnormalised posterior (a_j + eps)(f2_j + eps) -- no logarithm, no Gumbel transform
-      const int xt = load_tok(a.xt, n, a.xt_bytes);
+      const int xt = load_index(a.xt, n, a.xt_bytes, a.tb.K);
       const float a_d = dg(a.tb.qone_digest, t, 0, K)[xt] + eps, a_o = dg(a.tb.qone_digest, t, 1, K)[xt] + eps;
       float w[L::V];
 #pragma unroll
@@ -988,12 +987,12 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
         w[v] = c < K ? ((c == xt) ? a_d : a_o) * (f2 + eps) : 0.0f;
       }
       const U4 r = philox4x32_10((uint64_t)n, offset, seed);
-      const float uu = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+      const float uu = u01_open(r.x);
       besti = group_pick<L::G, L::V>(w, g, uu, xt, [](int gg, int vv) { return L::cls(gg, vv); });
       if (g == 0) sample[n] = besti;
       continue;
     } else {
-      const int xt = load_tok(a.xt, n, a.xt_bytes);
+      const int xt = load_index(a.xt, n, a.xt_bytes, a.tb.K);
       const float l1d = dg(a.tb.qone_digest, t, 2, K)[xt], l1o = dg(a.tb.qone_digest, t, 3, K)[xt];
       float u[L::V];
       load_slots<L>(noise + n * K, g, K, 0.5f, u);
@@ -1032,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK) void k_prior(ImgArgs a, int absorbing, float
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += BLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = load_tok(a.x0, n, a.x0_bytes);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, a.tb.K);
     float kl = 0;
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {

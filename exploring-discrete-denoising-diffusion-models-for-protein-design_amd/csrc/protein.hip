@@ -33,6 +33,11 @@ __device__ __forceinline__ void load_digest_d(const double* digest, int t, int c
 }
 
 // ------------------------------------------------------------------ forward corruption
+// The loss and the reverse step read Qbar_{t-1} and Q_t: their timesteps lie in [1, T - 1] (the loss also takes
+// t == tmax, which reads no table).  Anything else is brought to the nearest valid step, so nothing is read outside
+// the digests; tokens are clamped to [0, K - 1] in the same way.
+__device__ __forceinline__ int lvb_timestep(int t, int T) { return max(1, min(t, T - 1)); }
+
 template <class L>
 __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __restrict__ expo, uint64_t seed,
                                                     uint64_t offset, int64_t* __restrict__ x_t,
@@ -40,14 +45,14 @@ __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = (int)a.t[b];
+  const int t = clamp_index((int)a.t[b], a.tb.T);
   double d[L::V], o[L::V];
   load_digest_d<L>(a.tb.qbar_digest, t, 0, K, g, d);
   load_digest_d<L>(a.tb.qbar_digest, t, 1, K, g, o);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = (int)a.x0[n];
+    const int x0 = clamp_index((int)a.x0[n], K);
     double pv[L::V];
 #pragma unroll
     for (int v = 0; v < L::V; ++v) {
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = (int)a.t[b];
+  const int t0 = (int)a.t[b];
+  const int t = (t0 == tmax) ? t0 : lvb_timestep(t0, a.tb.T);
   const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
   double md[L::V], mo[L::V], lmd[L::V], lmo[L::V];
   if (branch == 2) {
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int x0 = (int)a.x0[n];
+    const int x0 = clamp_index((int)a.x0[n], K);
     float z[L::V];
     float gz[L::V];
 #pragma unroll
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
       // cancels inside the logarithm and log B_j, log den come from the digests, so a class costs one float64
       // log (of s_j) and, for the gradient, one reciprocal:
       //   term_j = post_j (log B_j - log den + log rsum - log s_j)
-      const int xt = (int)a.xt[n];
+      const int xt = clamp_index((int)a.xt[n], K);
       load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
       double p[L::V];
       softmax_f32_to_f64<L>(z, g, K, p);
@@ -337,8 +343,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   };
   unsigned base = pbeg + wave * 64;
   if (base < p1) issue(base);
-  int t = (int)a.t[b];
-  t = max(1, min(t, max(tmax, a.tb.T - 1)));                 // t outside [1, T) would read outside the digests
+  const int t0 = (int)a.t[b];
+  const int t = (t0 == tmax) ? t0 : lvb_timestep(t0, a.tb.T);
   const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
   float mo[K];
   float mdo = 0, sum_mo = 0;
@@ -527,14 +533,14 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_reverse(ProtArgs a, const float*
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int g = threadIdx.x % L::G, slot = threadIdx.x / L::G;
-  const int t = (int)a.t[b];
+  const int t = lvb_timestep((int)a.t[b], a.tb.T);
   double md[L::V], mo[L::V];
   load_digest_d<L>(a.tb.qbar_digest, t - 1, 0, K, g, md);
   load_digest_d<L>(a.tb.qbar_digest, t - 1, 1, K, g, mo);
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
-    const int xt = (int)a.xt[n];
+    const int xt = clamp_index((int)a.xt[n], K);
     float z[L::V];
     load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
     double p[L::V], A[L::V], r[L::V], rsum, e[L::V];
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(u, pbeg + u * STEP);
   }
-  const int t = (int)a.t[b];
+  const int t = lvb_timestep((int)a.t[b], a.tb.T);
   // Per-slot constants of the timestep.  Slots past K get zero weights and their logits are replaced by -inf on
   // arrival, so the loop carries no bounds checks; the divisor of the last class is folded into its two weights
   // (the draw is linear in them).
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
       float z[L::V];
 #pragma unroll
       for (int v = 0; v < L::V; ++v) z[v] = valid[v] ? zq[u][v] : -INFINITY;
-      const int xt = xq[u];
+      const int xt = clamp_index(xq[u], K);
       if (pos + PF * STEP - slot < p1) fetch(u, pos + PF * STEP);   // refill this stage (uniform condition)
       const uint32_t word = pool[wave][(it % REFILL) * TPW + tok_in_wave];
       float m = -INFINITY;
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(BLK) void k_lvb_reverse_device_noise(ProtArgs a, co
         for (int v = 0; v < L::V; ++v)
           if (cls(g, v) == K - 1 && pos < exclude_last_prefix) r[v] = 0.0f;
       }
-      const float u01v = ((float)(word >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+      const float u01v = u01_open(word);
       const int pick = group_pick<L::G, L::V>(r, g, u01v, xt, cls);
       if (g == 0 && pos < p1) out[(long)b * a.npos + pos] = pick;
     }
@@ -731,8 +737,7 @@ __global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float
   };
   unsigned base = pbeg + wave * 64;
   if (base < p1) issue(base);
-  int t = (int)a.t[b];
-  t = max(1, min(t, a.tb.T - 1));                            // t outside [1, T) would read outside the digests
+  const int t = lvb_timestep((int)a.t[b], a.tb.T);
   const float vd = lane < K ? (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[lane] : 0.0f;
   const float vo = lane < K ? (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[lane] : 0.0f;
   if (lane < K) {
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float
     const unsigned pos = base + lane;
     // the uniform of this token: Philox counter = global token index
     const U4 rnd = philox4x32_10((uint64_t)b * (uint64_t)a.npos + pos, offset, seed);
-    const float u = fmaf((float)(rnd.x >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f);   // in (0, 1)
+    const float u = u01_open(rnd.x);
     xt = (int)min((unsigned)xt, (unsigned)(K - 1));          // out-of-range tokens are clamped: nothing faults
     rows.deposit(img, lane);
     wave_lds_order();

@@ -17,6 +17,18 @@
  * element (H*W*C for images, L for sequences, D*L for MSAs); tensors are laid
  * out [B, npos, K] row-major.
  *
+ * Accepted ranges.  Tokens: [0, K-1].  Image-style timesteps (d3pm_q_*,
+ * d3pm_hybrid_loss, d3pm_p_sample, d3pm_prior_bpd): [0, T-1].  Protein-style
+ * timesteps: [0, T-1] for d3pm_corrupt; [1, T-1] for d3pm_lvb_reverse_step and
+ * d3pm_lvb_loss, which also takes t == tmax (that branch reads no table).
+ * The host cannot see these values without a synchronisation, so the kernels
+ * do not report violations: a value outside its range (64-bit values are
+ * read as their low 32 bits, signed) is replaced by the nearest valid one
+ * before it indexes anything (the reference would raise an
+ * index error, or wrap to the last matrix for t - 1 == -1), and the result is
+ * that of the clamped input.  No value of a token or timestep makes a kernel
+ * read or write outside the tables and tensors it was given.
+ *
  * Return value: D3PM_OK or an error code; d3pm_last_error() gives the message
  * of the calling thread's last failure.
  */

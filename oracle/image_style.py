@@ -135,16 +135,39 @@ def build_process(betas: torch.Tensor, kind: str, num_bits: int, bands: Optional
 # --------------------------------------------------------------------------
 # gathers
 # --------------------------------------------------------------------------
+# Arithmetic type after the gathers: float32, as in the reference.  Tests switch it to float64 (with float64
+# logits) to evaluate the same formulas on the same float32 table values without float32 rounding, which tells
+# how far the reference's own float32 results are from the exact value -- the floor below which two correct
+# float32 evaluations cannot be expected to agree.
+ARITH = torch.float32
+
+
+class arithmetic:
+    """``with arithmetic(torch.float64): ...`` -- evaluate in that type inside the block."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global ARITH
+        self.saved, ARITH = ARITH, self.dtype
+
+    def __exit__(self, *exc):
+        global ARITH
+        ARITH = self.saved
+        return False
+
+
 def rows_at(a: torch.Tensor, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """``_at`` (:205-226): f32 cast of the whole table, then a[t_b, x]."""
-    a = a.to(dtype=torch.float32)
+    a = a.to(dtype=torch.float32).to(ARITH)
     tb = t.unsqueeze(1).unsqueeze(-1).unsqueeze(-1)
     return a[tb, x]
 
 
 def contract_at(a: torch.Tensor, t: torch.Tensor, probs: torch.Tensor) -> torch.Tensor:
     """``_at_onehot`` (:229-247): probs @ a[t_b] as a broadcast matmul."""
-    a = a.to(dtype=torch.float32)
+    a = a.to(dtype=torch.float32).to(ARITH)
     return torch.matmul(probs, a[t, None, None, Ellipsis])
 
 
@@ -185,7 +208,7 @@ def posterior_logits(p: Process, x_start: torch.Tensor, x_t: torch.Tensor, t: to
         tzero = x_start
     else:
         f2 = rows_at(p.q_mats, t - 1, x_start)
-        tzero = torch.log(F.one_hot(x_start.to(torch.int64), num_classes=p.K).to(torch.float) + p.eps)
+        tzero = torch.log(F.one_hot(x_start.to(torch.int64), num_classes=p.K).to(ARITH) + p.eps)
     out = torch.log(f1 + p.eps) + torch.log(f2 + p.eps)
     tb = t.unsqueeze(1).unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
     return torch.where(tb == 0, tzero, out)

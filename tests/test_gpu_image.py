@@ -20,6 +20,13 @@ RTOL = 1e-5
 # is close to zero (late timesteps: 1e-4 and below) is only defined to a few
 # 1e-7 absolute.  Losses of ordinary size are held to RTOL.
 LOSS_ATOL = 5e-7
+# Absolute floor for gradients, as a fraction of the largest gradient element of the tensor.  A gradient element is
+# p_j (g_j - sum_i p_i g_i): a difference of terms of the size of the largest element, so float32 rounding leaves
+# an absolute error of that scale whatever the element's own size.  The reference's own float32 gradients on the
+# golden inputs differ from a float64 evaluation of the same formulas by up to 3.7e-7 of the largest element
+# (2e-4 relative on elements above a thousandth of it); test_oracle_golden.py measures that.  Elements are held
+# to RTOL above a floor of under three times that figure.
+GRAD_FLOOR = 1e-6
 # Table entries are probabilities in [0,1] built in float64; entries such as
 # diag = 1 - rowsum carry an absolute rounding of a few 1e-16 whatever their size.
 TABLE_ATOL = 1e-15
@@ -88,13 +95,13 @@ def check_downstream(d, g, own_tables=False):
         close(losses, g["losses_" + lt], atol=LOSS_ATOL, what="losses " + lt)
         (gr,) = torch.autograd.grad((losses * w).sum(), lg)
         ref = g["grad_w_" + lt]
-        close(gr, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what="grad " + lt)
+        close(gr, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what="grad " + lt)
     d.loss_type = "hybrid"
     s, probs = d.p_sample(lambda x, tt: logits, x=x_t, t=t, noise=noise2)
     check_tokens(s, g["p_sample"], g["p_sample_margin"], "p_sample")
     close(probs, g["p_sample_probs"], atol=1e-7, what="p_sample probs")
     if g["prior_bpd"].size:
-        close(d.prior_bpd(x0), g["prior_bpd"], rtol=1e-4, atol=LOSS_ATOL, what="prior_bpd")
+        close(d.prior_bpd(x0), g["prior_bpd"], atol=LOSS_ATOL, what="prior_bpd")
 
 
 def test_uniform_k32_golden(pkg):
@@ -185,7 +192,7 @@ def test_seeded_against_oracle_odd_shapes(pkg):
             loss.sum().backward()
             close(loss, loss_ref.detach().numpy(), atol=1e-6, what=f"loss {kind} K={K}")
             ref = lg_ref.grad.numpy().reshape(lg.shape)
-            close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
+            close(lg.grad, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {kind} K={K}")
 
 
 @pytest.mark.parametrize("kind,bits", [("uniform", 5), ("absorbing", 4), ("gaussian", 4), ("uniform", 3)])
@@ -212,7 +219,7 @@ def test_p_logits_gradient_against_oracle(pkg, kind, bits):
     close(ml, ml_ref.detach().numpy(), atol=1e-5, what="p_logits")
     (ml * W.to(DEV)).sum().backward()
     ref = z_ref.grad.numpy()
-    close(z_dev.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"d p_logits / d logits {kind}")
+    close(z_dev.grad, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"d p_logits / d logits {kind}")
     post = d.q_posterior_logits(z_dev, x_t.to(DEV), t.to(DEV), x_start_logits=True)
     assert post.requires_grad and torch.equal(post.detach(), ml.detach())
     with torch.no_grad():
@@ -291,7 +298,7 @@ def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
         close(loss, loss_ref.detach().numpy(), atol=1e-6, what=f"loss {kind} K={K}")
         close(vb + lam * ce, loss_ref.detach().numpy(), atol=1e-6, what=f"vb + lam ce {kind} K={K}")
         ref = logits.grad.numpy()
-        close(dl, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {kind} K={K}")
+        close(dl, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {kind} K={K}")
 
 
 @pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
@@ -323,7 +330,7 @@ def test_k256_matrix_core_tiles_against_oracle(pkg, B, L):
         (loss * w.to(DEV)).sum().backward()
         close(loss, loss_ref.detach().numpy(), atol=LOSS_ATOL, what=f"loss {lt}")
         ref = lg_ref.grad.numpy()
-        close(lg.grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"grad {lt}")
+        close(lg.grad, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {lt}")
     d.loss_type = "hybrid"
     post = d.q_posterior_logits(logits.to(DEV), xt_ref.to(DEV), t.to(DEV), x_start_logits=True)
     close(post, im.posterior_logits(p, logits, xt_ref, t, True).numpy(), atol=1e-5, what="posterior logits")
@@ -435,7 +442,7 @@ def test_calc_bpd_loop_golden(pkg):
     res = d.calc_bpd_loop(lambda x, t: (loc, ls), x_start=T_(g["x0"]), noise=T_(g["noises"]))
     assert res["vbterms"].shape == (3, 40)
     close(res["vbterms"], g["vbterms"], rtol=1e-5, atol=LOSS_ATOL, what="vbterms")
-    close(res["prior"], g["prior"], rtol=1e-4, atol=LOSS_ATOL, what="prior")
+    close(res["prior"], g["prior"], atol=LOSS_ATOL, what="prior")
     close(res["total"], g["total"], rtol=1e-5, atol=40 * LOSS_ATOL, what="total")
     # device noise: a different corruption draw, same expectation within Monte-Carlo spread of 10 positions
     res2 = d.calc_bpd_loop(lambda x, t: (loc, ls), x_start=T_(g["x0"]))
@@ -568,6 +575,50 @@ def test_graphed_p_sample_loop(pkg, kind, bits):
     assert r3.shape == shape
 
 
+@pytest.mark.parametrize("kind,bits", [("uniform", 5), ("uniform", 3), ("gaussian", 4), ("gaussian", 8)])
+def test_out_of_range_tokens_and_timesteps_are_clamped(pkg, kind, bits):
+    """Tokens outside [0, K-1] and timesteps outside [0, T-1] index nothing out of bounds: every operator returns
+    exactly what it returns for the values brought to the nearest valid one (uniform 5 bits: the token-per-lane loss
+    kernel; 3 bits: the lane-group kernels; gaussian: dense tables, 8 bits on the matrix cores)."""
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
+    K, T = 2 ** bits, 20
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.02, 0.3, T, "linear"), transition_mat_type=kind,
+                              num_bits=bits, transition_bands=None, model_prediction="x_start",
+                              model_output="logits", loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    gen = torch.Generator().manual_seed(5 + bits)
+    B, npos = 6, 96
+    x0 = torch.randint(0, K, (B, npos, 1, 1), generator=gen)
+    xt = torch.randint(0, K, (B, npos, 1, 1), generator=gen)
+    for a in (x0, xt):
+        a.view(-1)[::7] = -3
+        a.view(-1)[3::11] = K + 5
+    t = torch.tensor([-1, 0, T - 1, T, T + 100, 3], dtype=torch.int64)
+    noise = torch.rand(B, npos, 1, 1, K, generator=gen)
+    logits = torch.randn(B, npos, 1, 1, K, generator=gen)
+    fix = lambda a: a.clamp(0, K - 1)
+
+    def run(x0_, xt_, t_):
+        x0_, xt_, t_, nz, lg = (a.to(DEV) for a in (x0_, xt_, t_, noise, logits))
+        res = [d.q_probs(x0_, t_), d.q_sample(x0_, t_, nz), d.q_posterior_logits(x0_, xt_, t_, x_start_logits=False),
+               d.q_posterior_logits(lg, xt_, t_, x_start_logits=True), d.prior_bpd(x0_),
+               d.vb_terms_bpd(lambda x, tt: lg, x_start=x0_, x_t=xt_, t=t_)[0],
+               d.p_sample(lambda x, tt: lg, x=xt_, t=t_, noise=nz)[0]]
+        # the fused loss and its gradient, through the C ABI
+        tb = d.tables()
+        loss, dl = torch.empty(B, device=DEV), torch.empty_like(lg)
+        wsb = lib.d3pm_hybrid_loss_workspace(B, npos, K)
+        ws = torch.empty(max(wsb // 4, 1), device=DEV)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0_), 8, ptr(xt_), 8, ptr(t_), 8, B, npos, LOSS["hybrid"],
+                                   0.01, 1.0, None, None, None, ptr(loss), ptr(dl), None, None, 0, ptr(ws), wsb,
+                                   stream_ptr()))
+        torch.cuda.synchronize()
+        return res + [loss, dl]
+    got = run(x0, xt, t)
+    want = run(fix(x0), fix(xt), t.clamp(0, T - 1))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"output {i} differs"
+
+
 def test_empty_batch_and_errors(pkg):
     betas = pkg.generate_betas(0, 0, 10, "jsd")
     d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=3, transition_bands=None,
@@ -635,7 +686,7 @@ def test_full_size_properties(pkg):
         close(loss[sl], loss_ref.detach().numpy(), atol=LOSS_ATOL)
         (loss_ref.sum() / B).backward()
         ref = lg_ref.grad.numpy()
-        close(g[sl], ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        close(g[sl], ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max())
 
 
 def test_q_sample_device_noise_distribution(pkg):
@@ -694,7 +745,7 @@ def test_training_step_matches_separate_calls(pkg, kind, bits, B, L):
     ref.mean().backward()
     assert torch.equal(out["losses"], ref)
     close(out["loss"], ref.mean(), atol=LOSS_ATOL, what="batch mean")
-    close(logits.grad, ref_logits.grad, atol=1e-5 * float(ref_logits.grad.abs().max()), what="gradient")
+    close(logits.grad, ref_logits.grad, atol=GRAD_FLOOR * float(ref_logits.grad.abs().max()), what="gradient")
     # second step: fresh draw, the arrival counter was left clean
     logits.grad = None
     out2 = d.training_step(model_fn, x_start=x0, rng=(123, counter))

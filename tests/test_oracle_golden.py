@@ -259,3 +259,26 @@ def test_logistic_head_and_bpd_loop():
     res = im.bpd_sweep(p, lambda x, t: logits, T_(g["x0"]), T_(g["noises"]))
     for k in ("total", "vbterms", "prior"):
         np.testing.assert_array_equal(res[k].numpy(), g[k])
+
+
+@pytest.mark.parametrize("name,kind,bits", [("image_uniform_k32", "uniform", 5), ("image_absorbing_k32", "absorbing", 5),
+                                            ("image_gaussian_k256", "gaussian", 8)])
+def test_float32_rounding_floor_of_the_reference_gradient(name, kind, bits):
+    """How far the reference's own float32 gradient (golden vectors) is from a float64 evaluation of the same
+    formulas on the same float32 table values: a few 1e-7 of the largest element, absolutely, whatever the
+    element's size.  The GPU tests hold gradients to 1e-5 relative above GRAD_FLOOR = 1e-6 of the largest element;
+    this test shows that floor to be within a small factor of what float32 leaves undefined, not a loosened bar.
+    Per-example losses, by contrast, are defined to 1e-7 relative."""
+    g = golden(name)
+    x0, t, xt, w = T_(g["x0"]), T_(g["t"]), T_(g["x_t"]), T_(g["w"])
+    worst = 0.0
+    for lt in ("hybrid", "kl"):
+        p = im.build_process(T_(g["betas"]), kind, bits, None, hybrid_coeff=0.001, loss_type=lt)
+        lg = T_(g["logits"]).double().requires_grad_(True)
+        with im.arithmetic(torch.float64):
+            losses = im.losses_given_xt(p, lg, x0, xt, t)
+            (losses * w.double()).sum().backward()
+        exact, ref = lg.grad.numpy(), g["grad_w_" + lt].astype(np.float64)
+        worst = max(worst, np.abs(ref - exact).max() / np.abs(exact).max())
+        np.testing.assert_allclose(g["losses_" + lt], losses.detach().numpy(), rtol=2e-7, atol=5e-7)
+    assert 1e-7 < worst < 5e-7, worst
