@@ -43,7 +43,7 @@ SUB_BATCH = 1250               # reverse sampling: sequences per graph replay (1
 # HBM bytes per launch of a kernel from the PMC passes kept under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, gfx950
 # correction); the newest committed profile that names the kernel wins.  Not measured by this run: counters need a
 # rocprofv3 pass of their own.
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_kernels_pmc_hbm.json", "r01_bench_pmc_hbm.json")]
 
 
 def measured_traffic(kernel: str, must_contain: str = ""):

@@ -700,7 +700,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int KC, bool GRAD, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, int stagger) {
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, int stagger, int plog) {
   using C = TplCfg<KC>;
   extern __shared__ __align__(16) char tpl_rows[];          // [waves][64][STRIDE]
   __shared__ float red[2 * MAX_WAVES];
@@ -749,6 +749,7 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
   // (requested here, used after the first rows' softmax: the timestep -> digest chain is the longest latency of
   // the kernel's start, and that softmax does not need it)
   float boe[KC];
+  unsigned same_w = 0;          // bit q: classes 4q .. 4q+3 have one off-diagonal weight (all of them for uniform Q)
   float bdo = 0, sum_boe = 0;
   float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
   if (need_post && lane < KC) {
@@ -804,36 +805,51 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
         }
         bdo = lane_bcast(vd - vo, 0);
         sum_boe = wave_sum(lane < KC ? vboe : 0.0f);
+        int bits[KC];                           // scalar registers: the comparisons below are scalar too
 #pragma unroll
-        for (int j = 0; j < KC; ++j) boe[j] = lane_bcast(vboe, j);
+        for (int j = 0; j < KC; ++j) {
+          bits[j] = __builtin_amdgcn_readlane(__builtin_bit_cast(int, vboe), j);
+          boe[j] = __builtin_bit_cast(float, bits[j]);
+        }
+        unsigned sw = 0;
+#pragma unroll
+        for (int q = 0; q < KC / 4; ++q) {
+          const bool eq = bits[4 * q] == bits[4 * q + 1] && bits[4 * q] == bits[4 * q + 2] && bits[4 * q] == bits[4 * q + 3];
+          sw |= (eq ? 1u : 0u) << q;
+        }
+        same_w = __builtin_amdgcn_readfirstlane(sw);
       }
       wave_lds_fence();                       // this wave's table copy
       D3PM_TL(4);
     }
     if (!work) break;
     // ---- phase B
-    x0 = (int)min((unsigned)x0, (unsigned)(KC - 1));      // out-of-range tokens are clamped: nothing faults
-    xt = (int)min((unsigned)xt, (unsigned)(KC - 1));
+    x0 = clamp_index(x0, KC);                             // out-of-range tokens are clamped: nothing faults
+    xt = clamp_index(xt, KC);
     const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
     const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
     const bool live = base + lane < p1;
     const float ce_bits = fmaf(m - z_x0, LOG2E, l2s);     // -log2 softmax(z)[x0]
     acc_ce += live ? ce_bits : 0.0f;
-    float add0 = 0, addt = 0;
+    // gradient values of the two special classes, formed from per-token scalars and written over the row's
+    // generic values after the row has gone to LDS (plain stores in program order: no read-modify-write)
+    float g_x0 = 0, g_xt = 0;
+    const float e_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)), e_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg));
     if (!need_post) {
       acc_vb += live ? ce_bits : 0.0f;
       if constexpr (GRAD) {
         const float w = (t == 0 ? w_vb : 0.0f) + w_ce, wi = w * inv;
 #pragma unroll
         for (int j = 0; j < KC; ++j) e[j] *= wi;
-        add0 = -w;
+        g_x0 = fmaf(e_x0, wi, -w);
+        g_xt = (x0 == xt) ? g_x0 : e_xt * wi;
       }
     } else {
       const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt], da = a_d - a_o;
       const float boe_x0 = s_tab[wave][2][x0], boe_xt = s_tab[wave][2][xt];
       const float same = (x0 == xt) ? 1.0f : 0.0f;
       const float bdoi = bdo * inv;
-      const float pi_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)) * inv, pi_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg)) * inv;
+      const float pi_x0 = e_x0 * inv, pi_xt = e_xt * inv;
       const float f2_x0 = fmaf(bdo, pi_x0, boe_x0), f2_xt = fmaf(bdo, pi_xt, boe_xt);
       const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
       const float b_x0 = boe_x0 + bdo, b_xt = fmaf(same, bdo, boe_xt);
@@ -844,12 +860,26 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
       const float zr = Zm * izt;
       float pr[KC], E = 0, S1 = 0;
 #pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const float f2 = fmaf(e[j], bdoi, boe[j]);
-        pr[j] = boe[j] * fast_rcp(f2);                      // boe_j / f2_j
-        S1 = fmaf(boe[j], fast_log2(pr[j] * zr), S1);
-        if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
+      for (int q = 0; q < KC / 4; ++q) {
+#pragma unroll
+        for (int j = 4 * q; j < 4 * q + 4; ++j) {
+          const float f2 = fmaf(e[j], bdoi, boe[j]);
+          pr[j] = boe[j] * fast_rcp(f2);                    // boe_j / f2_j
+          if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
+        }
+        if (plog && ((same_w >> q) & 1)) {
+          // four classes of one weight w: sum_j w log2 pr_j = w log2 prod_j pr_j -- one logarithm.  Every pr_j lies in
+          // [off / (off + diag - off), 1] with off >= eps = 1e-6, so the product stays above 1e-24, inside the
+          // float32 range.  (The factor zr of every class is taken out of the sum: log2(zr) sum_j w_j below.  A term
+          // w log2 P is bounded by 4 w log2(1 / w), so taking the logarithms apart costs no accuracy that shows.)
+          const float P = (pr[4 * q] * pr[4 * q + 1]) * (pr[4 * q + 2] * pr[4 * q + 3]);
+          S1 = fmaf(boe[4 * q], fast_log2(P), S1);
+        } else {
+#pragma unroll
+          for (int j = 4 * q; j < 4 * q + 4; ++j) S1 = fmaf(boe[j], fast_log2(pr[j]), S1);
+        }
       }
+      S1 = fmaf(sum_boe, fast_log2(zr), S1);                // sum_j boe_j log2(pr_j zr)
       float kls = a_o * S1;
       kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
       kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
@@ -866,8 +896,9 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
         const float nA2i = -A2 * bdoi, Ci = inv * fmaf(bdo, A1, Cc);
 #pragma unroll
         for (int j = 0; j < KC; ++j) e[j] *= fmaf(nA2i, pr[j], Ci);
-        add0 = p0 - w_ce;
-        addt = pt;
+        g_x0 = fmaf(e_x0, fmaf(nA2i, boe_x0 * rf_x0, Ci), p0 - w_ce);
+        g_xt = fmaf(e_xt, fmaf(nA2i, boe_xt * rf_xt, Ci), pt);
+        if (x0 == xt) g_x0 = g_xt = g_x0 + pt;
       }
     }
     D3PM_TL_AFTER(5, e[KC - 1]);
@@ -876,20 +907,29 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
 #pragma unroll
       for (int j = 0; j < C::PIECES; ++j)
         *reinterpret_cast<v4f_nt*>(myrow + 16 * j) = v4f_nt{e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]};
-      *reinterpret_cast<float*>(myrow + 4 * x0) += add0;
-      *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
+      *reinterpret_cast<float*>(myrow + 4 * x0) = g_x0;
+      *reinterpret_cast<float*>(myrow + 4 * xt) = g_xt;
       wave_lds_fence();
 #ifdef D3PM_TIMELINE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       D3PM_TL(6);
 #endif
       const unsigned nrows = p1 - base;       // rows of this wave that exist
+      if (nrows >= 64) {                      // (uniform over the wave) the whole image, straight-line
 #pragma unroll
-      for (int h = 0; h < C::PIECES; ++h) {
-        const unsigned q = h * 64 + lane, r = q / C::PIECES, j = q % C::PIECES;
-        const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + r * C::STRIDE + j * 16);
-        if (r < nrows)
+        for (int h = 0; h < C::PIECES; ++h) {
+          const unsigned q = h * 64 + lane, r = q / C::PIECES, j = q % C::PIECES;
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + r * C::STRIDE + j * 16);
           __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * C::RB + j * 16)));
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < C::PIECES; ++h) {
+          const unsigned q = h * 64 + lane, r = q / C::PIECES, j = q % C::PIECES;
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + r * C::STRIDE + j * 16);
+          if (r < nrows)
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * C::RB + j * 16)));
+        }
       }
       D3PM_TL(7);
     }
@@ -1375,14 +1415,14 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
         if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       }
       static const int stagger = getenv("D3PM_STAGGER") ? atoi(getenv("D3PM_STAGGER")) : 0;
+      static const int plog = getenv("D3PM_LOSS_PLOG") ? atoi(getenv("D3PM_LOSS_PLOG")) : 1;   // 0: one logarithm per class
       hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale,
-                         grad_out, o, dlogits, stagger);
+                         grad_out, o, dlogits, stagger, plog);
       D3PM_LAUNCH_CHECK("k_hybrid_loss_tpl");
       return D3PM_OK;
     };
-    auto launch = [&](auto kc, auto grad) -> int {
-      return block <= 512 ? launch_t(kc, grad, std::integral_constant<int, 512>{})
-                          : launch_t(kc, grad, std::integral_constant<int, 1024>{});
+    auto launch = [&](auto kc, auto grad) -> int {          // block <= 512 always (see above)
+      return launch_t(kc, grad, std::integral_constant<int, 512>{});
     };
     auto by_grad = [&](auto kc) -> int {
       return dlogits ? launch(kc, std::true_type{}) : launch(kc, std::false_type{});

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   for (;; base += blockDim.x) {
     if (base >= p1) break;                                   // (uniform over the wave)
     const bool live = base + lane < p1;
-    x0 = (int)min((unsigned)x0, (unsigned)(K - 1));          // out-of-range tokens are clamped: nothing faults
-    xt = (int)min((unsigned)xt, (unsigned)(K - 1));
+    x0 = clamp_index(x0, K);                                 // out-of-range tokens are clamped: nothing faults
+    xt = clamp_index(xt, K);
     float e[LD];
     float tok_loss = 0, add0 = 0, addt = 0;
     if (branch == 1) {
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float
     // the uniform of this token: Philox counter = global token index
     const U4 rnd = philox4x32_10((uint64_t)b * (uint64_t)a.npos + pos, offset, seed);
     const float u = u01_open(rnd.x);
-    xt = (int)min((unsigned)xt, (unsigned)(K - 1));          // out-of-range tokens are clamped: nothing faults
+    xt = clamp_index(xt, K);                                 // out-of-range tokens are clamped: nothing faults
     rows.deposit(img, lane);
     wave_lds_order();
     float e[LD];

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Every hot kernel of the path at the shapes bench.py uses, launched eagerly through the C ABI (no HIP graphs, no
+denoiser, a handful of torch launches for set-up only): the program that the rocprofv3 passes kept under profiles/
+run.  Prints each kernel's average duration between two HIP events, back to back on the launch stream, and its
+fraction of the 8 TB/s HBM roofline for the algorithmic bytes named in the table below.
+
+    python tools/kprofile.py [--reps 200] [--only hybrid,lvb,...]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import d3pm_amd  # noqa: E402
+from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS  # noqa: E402
+from d3pm_amd.tables import protein_tables  # noqa: E402
+
+HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    sp = stream_ptr()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rows = []
+
+    def timed(name, fn, bytes_per_launch, what):
+        if only and name not in only:
+            return
+        import time
+        until = time.perf_counter() + 0.15          # sustained clocks before anything is timed
+        while time.perf_counter() < until:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.reps
+        gbs = bytes_per_launch / us / 1e3
+        rows.append({"name": name, "us": us, "GB/s": gbs, "frac_hbm": gbs / HBM_GBS, "what": what})
+        print(f"{name:18s} {us:8.2f} us  {gbs:8.1f} GB/s  {gbs / HBM_GBS:5.3f} of HBM peak   {what}", flush=True)
+
+    # ---- image-style, structured tables: B=256, L=512, K=32, T=500
+    B, L, K, T, lam = 256, 512, 32, 500, 0.001
+    betas = d3pm_amd.generate_betas(0.0, 0.0, T, "jsd")
+    x0 = torch.randint(0, K, (B, L, 1, 1), device=dev)
+    logits = torch.randn(B, L, 1, 1, K, device=dev)
+    dl = torch.empty_like(logits)
+    loss = torch.empty(B, device=dev)
+    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+    ws = torch.empty(max(wsb // 4, 1), device=dev)
+    t = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+    for kind in ("uniform", "absorbing"):
+        d = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=5, transition_bands=None,
+                                       model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                       hybrid_coeff=lam, device=dev)
+        tb = d.tables()
+        xt = d.q_sample(x0, t)
+
+        def hybrid(grad=True):
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                       LOSS["hybrid"], lam, 1.0 / B, None, None, None, ptr(loss),
+                                       ptr(dl) if grad else None, None, None, 0, ptr(ws), wsb, sp))
+        timed(f"hybrid_{kind}", hybrid, (8 * K + 16) * B * L, f"d3pm_hybrid_loss fwd+bwd, {kind} Q, 8K+16 B/token")
+        if kind == "uniform":
+            timed("hybrid_fwd", lambda: hybrid(False), (4 * K + 16) * B * L, "d3pm_hybrid_loss forward only, 4K+16 B/token")
+            timed("q_sample", lambda: d.q_sample(x0, t), 16 * B * L,
+                  "q_sample with device noise (facade call), 16 B/token")
+
+    # ---- protein-style: B=256, L=512, K=22, n_tokens=24; reverse step at 1250 x 263, n_tokens=22
+    tok = d3pm_amd.Tokenizer()
+    Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
+    ptab = protein_tables(Qt, Qb)
+    BP, LP, KP, LDP = 256, 512, 22, 24
+    x0p = torch.randint(0, KP, (BP, LP), device=dev)
+    tp = torch.randint(2, 500, (BP,), device=dev)
+    xtp = torch.empty_like(x0p)
+    predp = torch.randn(BP, LP, LDP, device=dev)
+    dpp = torch.empty_like(predp)
+    perp = torch.empty(BP, dtype=torch.float64, device=dev)
+    wsbp = lib.d3pm_lvb_loss_workspace(BP, LP, KP)
+    wsp = torch.empty(max(wsbp // 8, 1), dtype=torch.float64, device=dev)
+
+    def corrupt():
+        check(lib.d3pm_corrupt(ptab.desc(), ptr(x0p), ptr(tp), BP, LP, None, 1, 0, ptr(xtp), None, sp))
+
+    def lvb():
+        check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
+                                1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
+    corrupt()
+    timed("corrupt", corrupt, 16 * BP * LP, "d3pm_corrupt (device noise), 16 B/token")
+    timed("lvb", lvb, (8 * LDP + 16) * BP * LP, "d3pm_lvb_loss fwd+bwd, n_tokens=24, 8 ld+16 B/token")
+    NB, SL = 1250, 263
+    for ld in (22, 24):
+        xr = torch.randint(0, KP, (NB, SL), device=dev)
+        tr = torch.full((NB,), 250, dtype=torch.long, device=dev)
+        outr = torch.empty_like(xr)
+        frz = torch.randn(NB, SL, ld, device=dev)
+
+        def rev():
+            check(lib.d3pm_lvb_reverse_step(ptab.desc(), ptr(frz), ld, ptr(xr), ptr(tr), NB, SL, None, 7, 0, None, 1.0,
+                                            0, ptr(outr), sp))
+        timed(f"reverse_{ld}", rev, (4 * ld + 16) * NB * SL, f"d3pm_lvb_reverse_step (device noise), n_tokens={ld}, 4 ld+16 B/token")
+    print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()
