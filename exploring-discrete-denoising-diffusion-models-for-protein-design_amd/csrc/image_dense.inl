@@ -180,13 +180,11 @@ __device__ __forceinline__ void tile_contract(const float* __restrict__ M, int K
 // 16-byte LDS read and its B operands are coalesced 128-byte row pieces of M,
 // read straight from global memory (every wave needs different columns, so LDS
 // staging of M would add traffic, not save it) one group of four steps ahead.
-// `in` and `out` are LDS [TM][260]; they may be the same buffer.  Every output element starts from `init` (the
-// epsilon that the caller would otherwise add to each element afterwards).
+// `in` and `out` are LDS [TM][260]; they may be the same buffer.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int TM>
-__device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ M, const float* in, float* out,
-                                                      float init) {
+__device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ M, const float* in, float* out) {
   constexpr int K = 256, LDK = K + 4, RT = TM / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -196,7 +194,7 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[rt][ct][e] = init;
+      for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
   // M[128h + s][64w + r (+32)] through a buffer descriptor: per-lane 32-bit byte offset, the group's row offset in
   // a scalar register and the rest in the instruction's immediate field, so the loop carries no address registers
   const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, K * K * 4, 0x00020000);
@@ -396,17 +394,16 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       for (int v = 1; v < L::V; ++v) m = fmaxf(m, z[v]);
       m = group_max<L::G>(m);
       float sum = 0;
-      const float mneg = -m * LOG2E;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2(fmaf(z[v], LOG2E, mneg)); sum += pi[v]; }   // 0 on masked slots
+      for (int v = 0; v < L::V; ++v) { pi[v] = fast_exp2((z[v] - m) * LOG2E); sum += pi[v]; }   // 0 on masked slots
       sum = group_sum<L::G>(sum);
-      const float inv = fast_rcp(sum), inv_live = live ? inv : 0.0f;
+      const float inv = fast_rcp(sum);
       if constexpr (L::VEC) {      // whole 16-byte pieces: ds_write_b128
         float pn[L::V];
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           if constexpr (!MFMA) zkeep[ps][v] = z[v];
-          pn[v] = pi[v] * inv_live;
+          pn[v] = live ? pi[v] * inv : 0.0f;
         }
         store_slots<L>(s_pi + (size_t)tok * LDK, g, K, pn);
       } else {
@@ -414,13 +411,11 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         for (int v = 0; v < L::V; ++v) {
           zkeep[ps][v] = z[v];
           const int c = L::cls(g, v);
-          if (c < K) s_pi[(size_t)tok * LDK + c] = pi[v] * inv_live;
+          if (c < K) s_pi[(size_t)tok * LDK + c] = live ? pi[v] * inv : 0.0f;
         }
       }
       cekeep[ps] = 0;
       if constexpr (MODE == DENSE_LOSS) {
-        // (taking z[x0] from memory instead -- one 4-byte load per token -- makes the register allocator of this
-        // compiler spill 1.2 KB per lane in the matrix-core variant; the select + group sum stays)
         float zx0 = 0;
 #pragma unroll
         for (int v = 0; v < L::V; ++v) zx0 += (L::cls(g, v) == x0c[ps]) ? z[v] : 0.0f;
@@ -464,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         // the co-resident workgroup's per-token phase issues ahead of this stream of long matrix instructions,
         // which loses next to nothing by it
         __builtin_amdgcn_s_setprio(0);
-        tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2, eps);           // f2 + eps
+        tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
         __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
       } else tile_contract<L>(Qm, K, s_pi, s_f2);
     }
@@ -485,10 +480,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       if (need_post) {
         if (ps + 1 < NP) gather(ps + 1);
         load_slots<L>(s_f2 + (size_t)tok * LDK, g, K, 1.0f, f2e);
-        if constexpr (!MFMA) {             // (the matrix-core contraction starts its accumulators from eps)
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) f2e[v] += eps;
-        }
+        for (int v = 0; v < L::V; ++v) f2e[v] += eps;
       }
       if constexpr (MFMA && !GRAD) {
         if (ps == NP - 1 && more) fetch_tile(tile0 + C::TM);
@@ -512,13 +505,12 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
           zm = group_sum<L::G>(zm);
           zt = group_sum<L::G>(zt);
           const float izm = fast_rcp(zm), izt = fast_rcp(zt), zr = zm * izt;
-          const float g1 = live ? w_vb * izm : 0.0f, g2 = live ? -w_vb * izt : 0.0f;
           float kl = 0, gf2[L::V];
 #pragma unroll
           for (int v = 0; v < L::V; ++v) {
             const float br = bv[v] * fast_rcp(f2e[v]);                     // b_j / f2_j
             kl = fmaf(av[v] * bv[v], fast_log2(br * zr), kl);              // av = 0 on masked slots
-            if constexpr (GRAD) gf2[v] = av[v] * fmaf(br, g2, g1);         // w_vb a_j (1 / zm - (b_j / f2_j) / zt)
+            if constexpr (GRAD) gf2[v] = live ? w_vb * av[v] * fmaf(-br, izt, izm) : 0.0f;
           }
           if constexpr (GRAD) {
             if constexpr (L::VEC) {
@@ -598,7 +590,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       if (need_post) {
         if constexpr (MFMA) {
           __builtin_amdgcn_s_setprio(0);
-          tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp, 0.0f);
+          tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
           __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
         } else tile_contract<L>(QmT, K, s_f2, s_gp);
       }
@@ -614,9 +606,9 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         if constexpr (MFMA) {
           // softmax again from the re-read row (same max and 1 / sum: bit-identical to phase 1); the row after it,
           // or the next tile's first pass, is requested meanwhile
-          const float mneg = -s_tokf[3 * tok + 1] * LOG2E, inv = s_tokf[3 * tok + 2];
+          const float m = s_tokf[3 * tok + 1], inv = s_tokf[3 * tok + 2];
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) pi[v] = fast_exp2(fmaf(zn[ps % NZ][v], LOG2E, mneg)) * inv;
+          for (int v = 0; v < L::V; ++v) pi[v] = fast_exp2((zn[ps % NZ][v] - m) * LOG2E) * inv;
           if (ps + 1 < NP) fetch_row(tile0, ps + 1);
           else if (more) fetch_tile(tile0 + C::TM);
         }
@@ -629,9 +621,9 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
 #pragma unroll
           for (int v = 0; v < L::V; ++v) dot = fmaf(pi[v], gp[v], dot);
           dot = group_sum<L::G>(dot);
-          const float c = w_ce - dot;            // pi_j (gp_j - dot) + w_ce (pi_j - [j == x0])
 #pragma unroll
-          for (int v = 0; v < L::V; ++v) gz[v] = fmaf(pi[v], gp[v] + c, (L::cls(g, v) == x0) ? -w_ce : 0.0f);
+          for (int v = 0; v < L::V; ++v)
+            gz[v] = pi[v] * (gp[v] - dot) + w_ce * (pi[v] - ((L::cls(g, v) == x0) ? 1.0f : 0.0f));
         } else {
           const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
 #pragma unroll

@@ -1,0 +1,23 @@
+#!/bin/bash
+# The default bench on the GPU box, its JSON line kept under gpurun_out/ and summarised on stdout.
+mkdir -p gpurun_out
+OUT=gpurun_out/${1:-bench}.json
+shift
+timeout -k 10 400 python -u bench.py "$@" > $OUT 2> ${OUT%.json}.err
+rc=$?
+tail -c 400 ${OUT%.json}.err
+echo "rc=$rc"
+[ $rc -eq 0 ] || exit $rc
+python - "$OUT" <<'P'
+import json, sys
+d = json.load(open(sys.argv[1]))
+r = d["roofline"]
+print("value %.3e %s  ms/step %.4f  frac %.3f  rotating %s  kernel_ms %.5f  timed_s %.4f" % (
+    d["value"], d["unit"], d["ms_per_step"], r["frac"], r.get("frac_rotating_buffers"), r["kernel_ms"], d["config"]["timed_seconds"]))
+for k in ("absorbing", "reverse_sample", "image_k256", "protein_lvb"):
+    s = d.get(k)
+    if s:
+        print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in s.items() if a in ("value", "ms_per_step", "kernel_ms", "end_to_end_tiny_denoiser", "tokens_per_s")},
+              "frac %.3f" % s["roofline"]["frac"], "cpu", (s.get("cpu_baseline") or {}).get("value"))
+print("cpu_baseline", d.get("cpu_baseline"))
+P
