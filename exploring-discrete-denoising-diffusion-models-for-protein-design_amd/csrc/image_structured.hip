@@ -804,7 +804,9 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
           s_tab[wave][2][lane] = vboe;
         }
         bdo = lane_bcast(vd - vo, 0);
-        sum_boe = wave_sum(lane < KC ? vboe : 0.0f);
+        // every row of Qbar_{t-1} sums to one: diag_i + sum_{j != i} off_j = 1, so sum_j off_j = 1 - (diag - off) --
+        // no reduction over the classes
+        sum_boe = (1.0f - bdo) + (float)KC * eps;
         int bits[KC];                           // scalar registers: the comparisons below are scalar too
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
