@@ -958,6 +958,249 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
   D3PM_TL_FLUSH;
 }
 
+// ------------------------------------------------------------------ fused hybrid loss, K = 32, two lanes per token
+// The same arithmetic with a token on a pair of lanes (lane 2p + h holds classes 16h .. 16h + 15 of the wave's
+// token p): a wave takes 32 tokens, so a batch element of 512 positions is 16 waves -- four per SIMD instead of two,
+// which is what the vector ALUs need to issue back to back, and a finer pipeline of load / compute / store phases
+// over the chip.  The price: the per-token scalar work runs on both lanes, the per-class constants are per lane
+// (vector registers) and four sums per token cross the pair (one DPP operation each).  The LDS image holds the
+// wave's 64 half-rows at a stride of 80 bytes (odd multiple of 16).
+template <bool GRAD>
+__global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
+    ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
+  constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
+  extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
+  __shared__ float red[2 * PW];
+  __shared__ float s_tab[PW][3][KC];                        // as in k_hybrid_loss_tpl: a copy per wave
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x;                                 // one workgroup per batch element
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane & 1, ptok = lane >> 1;
+  const unsigned p1 = (unsigned)a.npos;
+  const unsigned step = blockDim.x >> 1;                    // tokens per pass of the workgroup
+  const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * KC);
+  char* __restrict__ drow = GRAD ? (char*)(dlogits + (size_t)b * a.npos * KC) : nullptr;
+  const char* __restrict__ x0row = (const char*)a.x0 + (size_t)b * a.npos * a.x0_bytes;
+  const char* __restrict__ xtrow = (const char*)a.xt + (size_t)b * a.npos * a.xt_bytes;
+  const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
+  char* const img = pair_rows + (size_t)wave * 64 * HS;
+  char* const myhalf = img + lane * HS;                     // half-row index = lane
+  char* const tokrow = img + (lane & ~1) * HS;              // class c of this token: tokrow + (c >> 4) * HS + 4 * (c & 15)
+  auto cls_off = [](int c) { return (c >> 4) * HS + 4 * (c & 15); };
+
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
+
+  v4f_nt stage[4];
+  int x0 = 0, xt = 0;
+  auto issue = [&](unsigned base) {           // base: first position of this wave's 32 tokens
+    const unsigned last = p1 - 1 - base;      // rows past the end re-read the last one (never stored)
+    const unsigned mine = min((unsigned)ptok, last);
+    x0 = *reinterpret_cast<const int*>(x0row + ((base + mine) << x0sh));
+    xt = *reinterpret_cast<const int*>(xtrow + ((base + mine) << xtsh));
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned q = h * 64 + lane, r = min(q / 8, last), j = q % 8;
+      stage[h] = *reinterpret_cast<const v4f_nt*>(lrow + ((base + r) * RB + j * 16));
+    }
+  };
+  unsigned base = wave * 32;
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);      // requested first: loads retire in issue order
+  if (base < p1) issue(base);
+  const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
+  float boe[HC];
+  unsigned same_w = 0;          // bit q: classes 4q .. 4q+3 of both halves have one off-diagonal weight each
+  float bdo = 0, sum_boe = 0;
+  float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
+  v4f_nt vb4[4] = {};
+  if (need_post) {
+    if (lane < KC) {
+      vd = dg(a.tb.qbar_digest, t - 1, 0, KC)[lane];
+      vo = dg(a.tb.qbar_digest, t - 1, 1, KC)[lane];
+      v_ad = dg(a.tb.qone_digest, t, 0, KC)[lane];
+      v_ao = dg(a.tb.qone_digest, t, 1, KC)[lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vb4[i] = *reinterpret_cast<const v4f_nt*>(dg(a.tb.qbar_digest, t - 1, 1, KC) + HC * half + 4 * i);
+  }
+  const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
+  const float cnorm = gb / ((float)a.npos * LN2);
+  const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
+  const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
+  float acc_vb = 0, acc_ce = 0;
+  bool first = true;
+  for (;; base += step) {
+    const bool work = base < p1;              // uniform over the wave
+    float e[HC];
+    float m = 0, inv = 0, l2s = 0, mneg = 0;
+    if (work) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const unsigned q = h * 64 + lane;
+        *reinterpret_cast<v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16) = stage[h];
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v4f_nt q = *reinterpret_cast<const v4f_nt*>(myhalf + 16 * j);
+        e[4 * j] = q.x; e[4 * j + 1] = q.y; e[4 * j + 2] = q.z; e[4 * j + 3] = q.w;
+      }
+      // ---- phase A: softmax statistics (no timestep needed)
+      m = e[0];
+#pragma unroll
+      for (int j = 1; j < HC; ++j) m = fmaxf(m, e[j]);
+      m = fmaxf(m, partner<1>(m));
+      mneg = -m * LOG2E;
+      float s_ = 0;
+#pragma unroll
+      for (int j = 0; j < HC; ++j) { e[j] = fast_exp2(fmaf(e[j], LOG2E, mneg)); s_ += e[j]; }
+      s_ += partner<1>(s_);
+      inv = fast_rcp(s_);
+      l2s = fast_log2(s_);
+    }
+    if (first) {
+      first = false;
+      if (need_post) {
+        if (lane < KC) {
+          s_tab[wave][0][lane] = v_ad + eps;
+          s_tab[wave][1][lane] = v_ao + eps;
+          s_tab[wave][2][lane] = vo + eps;
+        }
+        bdo = lane_bcast(vd - vo, 0);
+        sum_boe = (1.0f - bdo) + (float)KC * eps;           // rows of Qbar_{t-1} sum to one
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          boe[4 * i] = vb4[i].x + eps; boe[4 * i + 1] = vb4[i].y + eps;
+          boe[4 * i + 2] = vb4[i].z + eps; boe[4 * i + 3] = vb4[i].w + eps;
+        }
+        unsigned sw = 0;
+#pragma unroll
+        for (int q = 0; q < HC / 4; ++q) {
+          const bool eq = boe[4 * q] == boe[4 * q + 1] && boe[4 * q] == boe[4 * q + 2] && boe[4 * q] == boe[4 * q + 3];
+          sw |= (__builtin_amdgcn_ballot_w64(eq) == ~0ull ? 1u : 0u) << q;
+        }
+        same_w = __builtin_amdgcn_readfirstlane(sw);
+      }
+      wave_lds_fence();                       // this wave's table copy
+    }
+    if (!work) break;
+    // ---- phase B
+    x0 = clamp_index(x0, KC);
+    xt = clamp_index(xt, KC);
+    const float z_x0 = *reinterpret_cast<const float*>(tokrow + cls_off(x0));
+    const float z_xt = *reinterpret_cast<const float*>(tokrow + cls_off(xt));
+    const bool live = (base + ptok < p1) && half == 0;      // the token's sums are counted once
+    const float ce_bits = fmaf(m - z_x0, LOG2E, l2s);       // -log2 softmax(z)[x0]
+    acc_ce += live ? ce_bits : 0.0f;
+    float g_x0 = 0, g_xt = 0;
+    const float e_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)), e_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg));
+    if (!need_post) {
+      acc_vb += live ? ce_bits : 0.0f;
+      if constexpr (GRAD) {
+        const float w = (t == 0 ? w_vb : 0.0f) + w_ce, wi = w * inv;
+#pragma unroll
+        for (int j = 0; j < HC; ++j) e[j] *= wi;
+        g_x0 = fmaf(e_x0, wi, -w);
+        g_xt = (x0 == xt) ? g_x0 : e_xt * wi;
+      }
+    } else {
+      const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt], da = a_d - a_o;
+      const float boe_x0 = s_tab[wave][2][x0], boe_xt = s_tab[wave][2][xt];
+      const float same = (x0 == xt) ? 1.0f : 0.0f;
+      const float bdoi = bdo * inv;
+      const float pi_x0 = e_x0 * inv, pi_xt = e_xt * inv;
+      const float f2_x0 = fmaf(bdo, pi_x0, boe_x0), f2_xt = fmaf(bdo, pi_xt, boe_xt);
+      const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
+      const float b_x0 = boe_x0 + bdo, b_xt = fmaf(same, bdo, boe_xt);
+      const float a_x0 = fmaf(same, da, a_o);
+      const float Zt = fmaf(a_o, sum_boe + bdo, da * b_xt);
+      const float Zm = fmaf(a_o, sum_boe + bdo, da * f2_xt);
+      const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
+      const float zr = Zm * izt;
+      float pr[HC], E = 0, S1 = 0;
+#pragma unroll
+      for (int q = 0; q < HC / 4; ++q) {
+#pragma unroll
+        for (int j = 4 * q; j < 4 * q + 4; ++j) {
+          const float f2 = fmaf(e[j], bdoi, boe[j]);
+          pr[j] = boe[j] * fast_rcp(f2);
+          if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
+        }
+        if ((same_w >> q) & 1) {              // one logarithm for four classes of one weight (see k_hybrid_loss_tpl)
+          const float P = (pr[4 * q] * pr[4 * q + 1]) * (pr[4 * q + 2] * pr[4 * q + 3]);
+          S1 = fmaf(boe[4 * q], fast_log2(P), S1);
+        } else {
+#pragma unroll
+          for (int j = 4 * q; j < 4 * q + 4; ++j) S1 = fmaf(boe[j], fast_log2(pr[j]), S1);
+        }
+      }
+      S1 += partner<1>(S1);
+      if constexpr (GRAD) E += partner<1>(E);
+      S1 = fmaf(sum_boe, fast_log2(zr), S1);
+      float kls = a_o * S1;
+      kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
+      kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
+      kls = fmaf((1.0f - same) * da * boe_xt, fast_log2(boe_xt * rf_xt * zr), kls);
+      acc_vb += live ? kls * izt : 0.0f;
+      if constexpr (GRAD) {
+        const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
+        const float d_x0 = -A2 * bdo * rf_x0;
+        const float d_xt = w_vb * da * (izm - b_xt * rf_xt * izt);
+        const float p0 = pi_x0 * d_x0 * bdo, pt = pi_xt * d_xt * bdo;
+        const float D = bdo * (A1 - A2 * inv * E);
+        const float Cc = w_ce - (D + p0 + pt);
+        const float nA2i = -A2 * bdoi, Ci = inv * fmaf(bdo, A1, Cc);
+#pragma unroll
+        for (int j = 0; j < HC; ++j) e[j] *= fmaf(nA2i, pr[j], Ci);
+        g_x0 = fmaf(e_x0, fmaf(nA2i, boe_x0 * rf_x0, Ci), p0 - w_ce);
+        g_xt = fmaf(e_xt, fmaf(nA2i, boe_xt * rf_xt, Ci), pt);
+        if (x0 == xt) g_x0 = g_xt = g_x0 + pt;
+      }
+    }
+    if constexpr (GRAD) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<v4f_nt*>(myhalf + 16 * j) = v4f_nt{e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]};
+      if (half == 0) {                        // after both lanes' generic values (LDS executes a wave's writes in order)
+        *reinterpret_cast<float*>(tokrow + cls_off(x0)) = g_x0;
+        *reinterpret_cast<float*>(tokrow + cls_off(xt)) = g_xt;
+      }
+      wave_lds_fence();
+      const unsigned nrows = p1 - base;       // tokens of this wave that exist
+      if (nrows >= 32) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const unsigned q = h * 64 + lane, r = q / 8, j = q % 8;
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16);
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * RB + j * 16)));
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const unsigned q = h * 64 + lane, r = q / 8, j = q % 8;
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16);
+          if (r < nrows)
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * RB + j * 16)));
+        }
+      }
+    }
+    if (base + step >= p1) break;             // (uniform over the wave)
+    wave_lds_fence();
+    issue(base + step);
+  }
+  acc_vb = wave_sum(acc_vb);
+  acc_ce = wave_sum(acc_ce);
+  const int nw = blockDim.x >> 6;
+  if (lane == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float svb = 0, sce = 0;
+    for (int w = 0; w < nw; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
+    write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
+  }
+}
+
 // Sums of the per-workgroup partials in chunk order; `unit` converts them to
 // bits (1 for partials already in bits, 1/ln2 for partials in nats).
 __global__ void k_loss_finalize(LossOut out, int B, int chunks, long npos, int loss_type, float hybrid_coeff,
@@ -1407,6 +1650,25 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
       D3PM_CHECK_ARG(partials && partial_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
       o.part = partials;
+    }
+    static const int pair = getenv("D3PM_LOSS_PAIR") ? atoi(getenv("D3PM_LOSS_PAIR")) : 1;   // 0: one token per lane
+    if (pair && K == 32 && a.chunks == 1) {
+      // two lanes per token: 32 tokens per wave, up to 16 waves per workgroup
+      const long waves = (npos + 31) / 32;
+      const int pblock = (int)(waves > 16 ? 16 : waves) * 64;
+      const size_t sh = (size_t)(pblock / 64) * 64 * 80;
+      auto go = [&](auto grad) -> int {
+        auto kern = k_hybrid_loss_pair32<decltype(grad)::value>;
+        if (sh > 48 * 1024) {
+          hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+          if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        }
+        hipLaunchKernelGGL(kern, dim3(B), dim3(pblock), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale, grad_out,
+                           o, dlogits);
+        D3PM_LAUNCH_CHECK("k_hybrid_loss_pair32");
+        return D3PM_OK;
+      };
+      return dlogits ? go(std::true_type{}) : go(std::false_type{});
     }
     auto launch_t = [&](auto kc, auto grad, auto maxt) -> int {
       constexpr int KC = decltype(kc)::value;
