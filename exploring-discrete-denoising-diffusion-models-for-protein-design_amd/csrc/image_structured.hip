@@ -972,7 +972,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
   extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
   __shared__ float red[2 * PW];
-  __shared__ float s_tab[PW][3][KC];                        // as in k_hybrid_loss_tpl: a copy per wave
+  __shared__ __align__(16) float s_tab[PW][3][KC];          // as in k_hybrid_loss_tpl: a copy per wave
   const float eps = a.tb.eps;
   const int b = blockIdx.x;                                 // one workgroup per batch element
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -991,6 +991,8 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
 
   if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
 
+  D3PM_TL_DECL;
+  D3PM_TL(0);
   v4f_nt stage[4];
   int x0 = 0, xt = 0;
   auto issue = [&](unsigned base) {           // base: first position of this wave's 32 tokens
@@ -1007,23 +1009,21 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   unsigned base = wave * 32;
   const int t = load_index(a.t, b, a.t_bytes, a.tb.T);      // requested first: loads retire in issue order
   if (base < p1) issue(base);
+  D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
-  float boe[HC];
+  float s1_const = 0;           // sum over the one-weight groups of this lane's half of 4 w log2 w
   unsigned same_w = 0;          // bit q: classes 4q .. 4q+3 of both halves have one off-diagonal weight each
   float bdo = 0, sum_boe = 0;
   float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
-  v4f_nt vb4[4] = {};
-  if (need_post) {
-    if (lane < KC) {
-      vd = dg(a.tb.qbar_digest, t - 1, 0, KC)[lane];
-      vo = dg(a.tb.qbar_digest, t - 1, 1, KC)[lane];
-      v_ad = dg(a.tb.qone_digest, t, 0, KC)[lane];
-      v_ao = dg(a.tb.qone_digest, t, 1, KC)[lane];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vb4[i] = *reinterpret_cast<const v4f_nt*>(dg(a.tb.qbar_digest, t - 1, 1, KC) + HC * half + 4 * i);
+  if (need_post && lane < KC) {
+    vd = dg(a.tb.qbar_digest, t - 1, 0, KC)[lane];
+    vo = dg(a.tb.qbar_digest, t - 1, 1, KC)[lane];
+    v_ad = dg(a.tb.qone_digest, t, 0, KC)[lane];
+    v_ao = dg(a.tb.qone_digest, t, 1, KC)[lane];
   }
+  // this lane's per-class weights off_j + eps stay in the wave's LDS table and are read four at a time (a broadcast
+  // read per group): sixteen registers less than keeping them, which is what this kernel is short of
+  const v4f_nt* const my_boe = reinterpret_cast<const v4f_nt*>(&s_tab[wave][2][HC * half]);
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
   const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         const unsigned q = h * 64 + lane;
         *reinterpret_cast<v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16) = stage[h];
       }
+      if (first) D3PM_TL(2);
       wave_lds_fence();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1058,6 +1059,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       s_ += partner<1>(s_);
       inv = fast_rcp(s_);
       l2s = fast_log2(s_);
+      if (first) D3PM_TL_AFTER(3, l2s);
     }
     if (first) {
       first = false;
@@ -1069,20 +1071,21 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         }
         bdo = lane_bcast(vd - vo, 0);
         sum_boe = (1.0f - bdo) + (float)KC * eps;           // rows of Qbar_{t-1} sum to one
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          boe[4 * i] = vb4[i].x + eps; boe[4 * i + 1] = vb4[i].y + eps;
-          boe[4 * i + 2] = vb4[i].z + eps; boe[4 * i + 3] = vb4[i].w + eps;
-        }
+        wave_lds_fence();                     // this wave's table copy
         unsigned sw = 0;
+        s1_const = 0;
 #pragma unroll
         for (int q = 0; q < HC / 4; ++q) {
-          const bool eq = boe[4 * q] == boe[4 * q + 1] && boe[4 * q] == boe[4 * q + 2] && boe[4 * q] == boe[4 * q + 3];
-          sw |= (__builtin_amdgcn_ballot_w64(eq) == ~0ull ? 1u : 0u) << q;
+          const v4f_nt w = my_boe[q];
+          const bool eq = w.x == w.y && w.x == w.z && w.x == w.w;
+          const bool all = __builtin_amdgcn_ballot_w64(eq) == ~0ull;
+          sw |= (all ? 1u : 0u) << q;
+          if (all) s1_const = fmaf(4.0f * w.x, fast_log2(w.x), s1_const);
         }
         same_w = __builtin_amdgcn_readfirstlane(sw);
       }
-      wave_lds_fence();                       // this wave's table copy
+      wave_lds_fence();
+      D3PM_TL(4);
     }
     if (!work) break;
     // ---- phase B
@@ -1121,20 +1124,29 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       float pr[HC], E = 0, S1 = 0;
 #pragma unroll
       for (int q = 0; q < HC / 4; ++q) {
+        // the four reciprocals 1 / f2_j from one: r = 1 / (f0 f1 f2 f3), 1 / f0 = r (f2 f3) f1, ...  A transcendental
+        // costs four ordinary operations on this part; every f2_j lies in [eps, 2], so the product stays in range.
+        const v4f_nt w = my_boe[q];
+        const float f0 = fmaf(e[4 * q], bdoi, w.x), f1 = fmaf(e[4 * q + 1], bdoi, w.y);
+        const float f2 = fmaf(e[4 * q + 2], bdoi, w.z), f3 = fmaf(e[4 * q + 3], bdoi, w.w);
+        const float p01 = f0 * f1, p23 = f2 * f3, r = fast_rcp(p01 * p23);
+        const float r01 = r * p23, r23 = r * p01;
+        pr[4 * q] = w.x * (r01 * f1);
+        pr[4 * q + 1] = w.y * (r01 * f0);
+        pr[4 * q + 2] = w.z * (r23 * f3);
+        pr[4 * q + 3] = w.w * (r23 * f2);
+        if constexpr (GRAD) {
 #pragma unroll
-        for (int j = 4 * q; j < 4 * q + 4; ++j) {
-          const float f2 = fmaf(e[j], bdoi, boe[j]);
-          pr[j] = boe[j] * fast_rcp(f2);
-          if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
+          for (int j = 4 * q; j < 4 * q + 4; ++j) E = fmaf(e[j], pr[j], E);
         }
         if ((same_w >> q) & 1) {              // one logarithm for four classes of one weight (see k_hybrid_loss_tpl)
-          const float P = (pr[4 * q] * pr[4 * q + 1]) * (pr[4 * q + 2] * pr[4 * q + 3]);
-          S1 = fmaf(boe[4 * q], fast_log2(P), S1);
+          S1 = fmaf(w.x, fast_log2(r), S1);                         // prod_j pr_j = w^4 r; the w^4 part is in s1_const
         } else {
 #pragma unroll
-          for (int j = 4 * q; j < 4 * q + 4; ++j) S1 = fmaf(boe[j], fast_log2(pr[j]), S1);
+          for (int j = 0; j < 4; ++j) S1 = fmaf(w[j], fast_log2(pr[4 * q + j]), S1);
         }
       }
+      S1 += s1_const;
       S1 += partner<1>(S1);
       if constexpr (GRAD) E += partner<1>(E);
       S1 = fmaf(sum_boe, fast_log2(zr), S1);
@@ -1158,6 +1170,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         if (x0 == xt) g_x0 = g_xt = g_x0 + pt;
       }
     }
+    D3PM_TL_AFTER(5, e[HC - 1]);
     if constexpr (GRAD) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1167,6 +1180,10 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         *reinterpret_cast<float*>(tokrow + cls_off(xt)) = g_xt;
       }
       wave_lds_fence();
+#ifdef D3PM_TIMELINE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      D3PM_TL(6);
+#endif
       const unsigned nrows = p1 - base;       // tokens of this wave that exist
       if (nrows >= 32) {
 #pragma unroll
@@ -1185,6 +1202,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         }
       }
     }
+    D3PM_TL(8);
     if (base + step >= p1) break;             // (uniform over the wave)
     wave_lds_fence();
     issue(base + step);
@@ -1199,6 +1217,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     for (int w = 0; w < nw; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
     write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
   }
+  D3PM_TL_FLUSH;
 }
 
 // Sums of the per-workgroup partials in chunk order; `unit` converts them to

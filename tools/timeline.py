@@ -66,7 +66,7 @@ names = ["start", "t loaded", "digest rows arrived", "after barrier", "loop entr
          "first token pass done", "loop exit", "kernel end"]
 if os.environ.get("D3PM_LOSS_V", "3") == "3":       # the token-per-lane kernel
     names = ["start", "t loaded", "rows arrived, staged in LDS", "phase A done", "tables staged",
-             "phase B arithmetic done", "gradient rows in LDS, patched", "coalesced pieces read back",
+             "phase B arithmetic done", "gradient rows in LDS, patched", "(unused)",
              "global stores issued"]
 nw = int((tl[0, :, 0] != 0).sum())
 t0 = tl[:, :nw, 0].min()
