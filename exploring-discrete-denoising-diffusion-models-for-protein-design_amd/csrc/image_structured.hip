@@ -968,7 +968,8 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
 template <bool GRAD>
 __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float per_pos_bits) {
+  // per_pos_bits = 1 / (npos ln 2), formed on the host: the kernel runs its set-up once per wave of 32 tokens
   constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
   extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
   __shared__ float red[2 * PW];
@@ -995,15 +996,23 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   D3PM_TL(0);
   v4f_nt stage[4];
   int x0 = 0, xt = 0;
+  // The wave's 32 rows are 4 KB of contiguous memory: piece h of a lane is at byte h * 1024 + 16 * lane of it.
+  const unsigned lane16 = lane * 16;
   auto issue = [&](unsigned base) {           // base: first position of this wave's 32 tokens
     const unsigned last = p1 - 1 - base;      // rows past the end re-read the last one (never stored)
     const unsigned mine = min((unsigned)ptok, last);
     x0 = *reinterpret_cast<const int*>(x0row + ((base + mine) << x0sh));
     xt = *reinterpret_cast<const int*>(xtrow + ((base + mine) << xtsh));
+    if (last >= 31) {                         // (uniform over the wave) all 32 rows exist
+      const char* src = lrow + (size_t)base * RB + lane16;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const unsigned q = h * 64 + lane, r = min(q / 8, last), j = q % 8;
-      stage[h] = *reinterpret_cast<const v4f_nt*>(lrow + ((base + r) * RB + j * 16));
+      for (int h = 0; h < 4; ++h) stage[h] = *reinterpret_cast<const v4f_nt*>(src + h * 1024);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const unsigned q = h * 64 + lane, r = min(q / 8, last), j = q % 8;
+        stage[h] = *reinterpret_cast<const v4f_nt*>(lrow + ((base + r) * RB + j * 16));
+      }
     }
   };
   unsigned base = wave * 32;
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   // read per group): sixteen registers less than keeping them, which is what this kernel is short of
   const v4f_nt* const my_boe = reinterpret_cast<const v4f_nt*>(&s_tab[wave][2][HC * half]);
   const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
-  const float cnorm = gb / ((float)a.npos * LN2);
+  const float cnorm = gb * per_pos_bits;
   const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
   const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
   float acc_vb = 0, acc_ce = 0;
@@ -1186,11 +1195,12 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
 #endif
       const unsigned nrows = p1 - base;       // tokens of this wave that exist
       if (nrows >= 32) {
+        char* dst = drow + (size_t)base * RB + lane16;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const unsigned q = h * 64 + lane, r = q / 8, j = q % 8;
+          const unsigned q = h * 64 + lane;
           const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16);
-          __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * RB + j * 16)));
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(dst + h * 1024));
         }
       } else {
 #pragma unroll
@@ -1683,7 +1693,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
           if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         }
         hipLaunchKernelGGL(kern, dim3(B), dim3(pblock), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale, grad_out,
-                           o, dlogits);
+                           o, dlogits, (float)(1.0 / ((double)npos * 0.6931471805599453)));
         D3PM_LAUNCH_CHECK("k_hybrid_loss_pair32");
         return D3PM_OK;
       };
