@@ -1020,7 +1020,6 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   if (base < p1) issue(base);
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
-  float s1_const = 0;           // sum over the one-weight groups of this lane's half of 4 w log2 w
   unsigned same_w = 0;          // bit q: classes 4q .. 4q+3 of both halves have one off-diagonal weight each
   float bdo = 0, sum_boe = 0;
   float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
@@ -1082,14 +1081,12 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         sum_boe = (1.0f - bdo) + (float)KC * eps;           // rows of Qbar_{t-1} sum to one
         wave_lds_fence();                     // this wave's table copy
         unsigned sw = 0;
-        s1_const = 0;
 #pragma unroll
         for (int q = 0; q < HC / 4; ++q) {
           const v4f_nt w = my_boe[q];
           const bool eq = w.x == w.y && w.x == w.z && w.x == w.w;
           const bool all = __builtin_amdgcn_ballot_w64(eq) == ~0ull;
           sw |= (all ? 1u : 0u) << q;
-          if (all) s1_const = fmaf(4.0f * w.x, fast_log2(w.x), s1_const);
         }
         same_w = __builtin_amdgcn_readfirstlane(sw);
       }
@@ -1149,13 +1146,13 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
           for (int j = 4 * q; j < 4 * q + 4; ++j) E = fmaf(e[j], pr[j], E);
         }
         if ((same_w >> q) & 1) {              // one logarithm for four classes of one weight (see k_hybrid_loss_tpl)
-          S1 = fmaf(w.x, fast_log2(r), S1);                         // prod_j pr_j = w^4 r; the w^4 part is in s1_const
+          const float w2 = w.x * w.x;
+          S1 = fmaf(w.x, fast_log2((w2 * w2) * r), S1);             // prod_j pr_j = w^4 / (f0 f1 f2 f3) >= 1e-24
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) S1 = fmaf(w[j], fast_log2(pr[4 * q + j]), S1);
         }
       }
-      S1 += s1_const;
       S1 += partner<1>(S1);
       if constexpr (GRAD) E += partner<1>(E);
       S1 = fmaf(sum_boe, fast_log2(zr), S1);
@@ -1217,8 +1214,12 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     wave_lds_fence();
     issue(base + step);
   }
-  acc_vb = wave_sum(acc_vb);
-  acc_ce = wave_sum(acc_ce);
+  // wave totals without the LDS crossbar: rows of 16 lanes by DPP, the four row totals through scalar registers
+  // (this is the tail of the wave's only pass: its latency is not covered by anything)
+  acc_vb = group_sum<16>(acc_vb);
+  acc_ce = group_sum<16>(acc_ce);
+  acc_vb = (lane_bcast(acc_vb, 0) + lane_bcast(acc_vb, 16)) + (lane_bcast(acc_vb, 32) + lane_bcast(acc_vb, 48));
+  acc_ce = (lane_bcast(acc_ce, 0) + lane_bcast(acc_ce, 16)) + (lane_bcast(acc_ce, 32) + lane_bcast(acc_ce, 48));
   const int nw = blockDim.x >> 6;
   if (lane == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
   __syncthreads();
