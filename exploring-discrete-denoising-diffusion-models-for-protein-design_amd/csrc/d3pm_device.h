@@ -205,13 +205,29 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t counter, uint64_t stream_id
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // (one 32 x 32 -> 64 bit multiply per product: v_mad_u64_u32 gives both halves)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return U4{c0, c1, c2, c3};
+}
+// Philox2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): a 64-bit counter and a 32-bit key,
+// one multiply per round -- half the work of the 4x32 form per call, for kernels that need one word per token.
+struct U2 { uint32_t x, y; };
+__device__ __forceinline__ U2 philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p = (uint64_t)0xD256D193u * c0;
+    const uint32_t n0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
+    c0 = n0;
+    key += 0x9E3779B9u;
+  }
+  return U2{c0, c1};
 }
 // U[0,1) with 24 random bits, like torch.rand for float32.
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }

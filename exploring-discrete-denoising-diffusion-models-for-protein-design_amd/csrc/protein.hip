@@ -806,6 +806,134 @@ __global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float
   }
 }
 
+// ------------------------------------------------------------------ reverse step, device noise, tokens of the whole batch in one row
+// The same draw as k_lvb_reverse_tpl with the [B, npos] tokens taken as one flat sequence: wave w owns tokens
+// 64 w .. 64 w + 63 wherever the batch elements begin, so a length that is no multiple of 64 (263 = 4 x 64 + 7)
+// leaves no idle lanes except in the launch's very last wave.  With npos >= 64 a wave touches at most two batch
+// elements; if their timesteps differ the per-timestep part runs once for each with the other's lanes masked (the
+// samplers step every sequence at one timestep, so this is the rare path).  No workgroup-level step: waves are
+// independent and a workgroup is only a launch unit.
+//   * rows: the wave's 64 rows are one contiguous block, addressed without any division (request_flat);
+//   * weights: with P2_j = sum_{i<=j} e_i^2 (the running sum of the softmax pass itself) and MO_j = sum_{i<=j} mo_i
+//     (per timestep, wave-uniform) the cumulative weight of classes 0..j is MO_j + c3 P2_j: one fused multiply-add
+//     and one compare per class, no second running sum;
+//   * noise: one 32-bit word per token from Philox2x32-10, keyed per launch by a Philox4x32-10 call on
+//     (offset, seed) that the scalar unit evaluates (its inputs are uniform).
+template <int K, int LD>
+__global__ __launch_bounds__(256) void k_lvb_reverse_flat(ProtArgs a, const float* __restrict__ pred, uint64_t seed,
+                                                          uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                          float last_class_div, long exclude_last_prefix,
+                                                          int64_t* __restrict__ out, unsigned ntok, float inv_npos) {
+  using Img = RowImage<LD>;
+  constexpr float LOG2E = 1.44269504088896340736f;
+  extern __shared__ __align__(16) char flat_rows[];         // [waves][64][STRIDE]
+  __shared__ float s_tab[4][3][32];                         // per wave: a_diag, a_off of Q_t by x_t; mo by class
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
+  if (base >= ntok) return;                                 // (uniform over the wave; the kernel has no barrier)
+  const unsigned np = (unsigned)a.npos;
+  // batch element and position of the wave's first token: float quotient, off by one at most (B <= 2^20)
+  unsigned b0 = __builtin_amdgcn_readfirstlane((unsigned)((float)base * inv_npos));
+  int r0 = (int)(base - b0 * np);
+  if (r0 < 0) { b0 -= 1; r0 += (int)np; }
+  else if (r0 >= (int)np) { b0 += 1; r0 -= (int)np; }
+  unsigned pos = (unsigned)r0 + lane;
+  const bool second = pos >= np;                            // this lane's token belongs to batch element b0 + 1
+  if (second) pos -= np;
+  const unsigned nrows = min(64u, ntok - base);
+  const bool spans = (unsigned)r0 + nrows > np;             // (uniform)
+  char* const img = flat_rows + (size_t)wave * Img::BYTES;
+  Img rows;
+  rows.request_flat((const char*)pred + (size_t)base * Img::RB, nrows * Img::RB - Img::PB, lane, nrows == 64);
+  int xt = (int)a.xt[base + min((unsigned)lane, nrows - 1)];
+  const int t0 = lvb_timestep((int)a.t[b0], a.tb.T);
+  const int t1 = spans ? lvb_timestep((int)a.t[b0 + 1], a.tb.T) : t0;
+  const bool two = t1 != t0;                                // (uniform)
+  float vd = 0, vo = 0, ad = 0, ao = 0;
+  auto fetch = [&](int t) {
+    if (lane < K) {
+      vd = (float)dgd(a.tb.qbar_digest, t - 1, 0, K)[lane];
+      vo = (float)dgd(a.tb.qbar_digest, t - 1, 1, K)[lane];
+      ad = (float)dgd(a.tb.qone_digest, t, 0, K)[lane];
+      ao = (float)dgd(a.tb.qone_digest, t, 1, K)[lane];
+    }
+  };
+  fetch(t0);
+  // the uniform of this token
+  if (offset_dev) offset += *offset_dev;
+  const U4 pad = philox4x32_10(offset, 0x243F6A8885A308D3ull, seed);
+  const U2 rnd = philox2x32_10((base + lane) ^ pad.x, pad.y, pad.z);
+  const float u = u01_open(rnd.x);
+  xt = clamp_index(xt, K);                                   // out-of-range tokens are clamped: nothing faults
+  rows.deposit_flat(img, lane, Img::split(lane));
+  wave_lds_order();
+  float z[LD];
+  Img::read_row(img, lane, z);
+  const float z_xt = *reinterpret_cast<const float*>(img + lane * Img::STRIDE + 4 * xt);
+  float m = z[0];
+#pragma unroll
+  for (int j = 1; j < K; ++j) m = fmaxf(m, z[j]);
+  const float mneg = -m * LOG2E;
+  float P2[K];                                               // running sums of e_j^2
+  float acc = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const float ej = __builtin_amdgcn_exp2f(fmaf(z[j], LOG2E, mneg));
+    acc = fmaf(ej, ej, acc);
+    P2[j] = acc;
+  }
+  const float e2_last = P2[K - 1] - P2[K - 2];
+  const float e_xt = __builtin_amdgcn_exp2f(fmaf(z_xt, LOG2E, mneg));
+  const float inv_e2 = __builtin_amdgcn_rcpf(acc);
+  const float inv_last = 1.0f / last_class_div;
+  const float w_last = (long)pos < exclude_last_prefix ? 0.0f : inv_last;
+  int pick = 0;
+  auto draw = [&]() {
+    // per-timestep constants from the lanes that fetched them
+    if (lane < 32) {
+      s_tab[wave][0][lane] = ad;
+      s_tab[wave][1][lane] = ao;
+      s_tab[wave][2][lane] = vo;
+    }
+    const float mdo = lane_broadcast(vd - vo, 0);
+    float sc = vo;                                           // inclusive scan of mo over the lanes (zero from lane K on)
+    sc += dpp_mov<0x111>(sc);                                // row_shr 1, 2, 4, 8: lanes without a source read zero
+    sc += dpp_mov<0x112>(sc);
+    sc += dpp_mov<0x114>(sc);
+    sc += dpp_mov<0x118>(sc);
+    const float row0 = lane_broadcast(sc, 15);
+    if (lane >= 16) sc += row0;
+    float MO[K - 1];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) MO[j] = lane_broadcast(sc, j);
+    const float mo_last = lane_broadcast(vo, K - 1);
+    wave_lds_order();
+    const float c3 = mdo * inv_e2;
+    const float g_last = fmaf(e2_last, c3, mo_last) * w_last;
+    const float G = fmaf(P2[K - 2], c3, MO[K - 2]) + g_last;
+    const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt];
+    const float g_xt = fmaf(e_xt * e_xt, c3, s_tab[wave][2][xt]) * (xt == K - 1 ? w_last : 1.0f);
+    const float X = (a_d - a_o) * __builtin_amdgcn_rcpf(a_o) * g_xt;
+    const float target = u * (G + X) - X;                    // < 0: the extra mass of x_t was hit
+    int cnt = 0;                                             // classes whose cumulative weight is <= target
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) cnt += (fmaf(P2[j], c3, MO[j]) <= target) ? 1 : 0;
+    int p = target < 0.0f ? xt : cnt;
+    // rounding can carry the count onto a class of zero weight (the excluded last class): step back
+    if (p == K - 1 && w_last == 0.0f) p = K - 2;
+    return p;
+  };
+  pick = draw();
+  if (two) {                                                 // (uniform) the wave's second batch element, own timestep
+    wave_lds_order();
+    fetch(t1);
+    const int p1 = draw();
+    pick = second ? p1 : pick;
+  }
+  if (lane < (int)nrows) out[base + lane] = pick;
+}
+
 static int check_prot(const d3pm_tables_f64* tb, int B, long npos) {
   D3PM_CHECK_ARG(tb && tb->qbar_digest && tb->qone_digest, "tables descriptor or digest is null");
   D3PM_CHECK_ARG(tb->K >= 2 && tb->K <= 256 && tb->T >= 1, "need 2 <= K <= 256, T >= 1 (K=%d, T=%d)", tb->K, tb->T);
@@ -937,6 +1065,27 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
   D3PM_CHECK_ARG(npos * ld < 0x1fffffffL, "one batch element spans %ld predictions: more than 2^29", npos * ld);
   static const bool allow_tpl = !(getenv("D3PM_REV_OLD") && atoi(getenv("D3PM_REV_OLD")));
+  static const bool allow_flat = !(getenv("D3PM_REV_FLAT") && !atoi(getenv("D3PM_REV_FLAT")));
+  if (allow_tpl && allow_flat && !expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+      npos >= 64 && B <= (1 << 20) && (long)B * npos * ld < 0x3fffffffL) {
+    // tokens of the whole batch as one row, 64 per wave
+    ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, 1);
+    const unsigned ntok = (unsigned)((long)B * npos);
+    const unsigned waves = (ntok + 63) / 64;
+    static const int flat_block = getenv("D3PM_REV_FLAT_BLOCK") ? atoi(getenv("D3PM_REV_FLAT_BLOCK")) : 256;
+    const int block = (flat_block == 64 || flat_block == 128) ? flat_block : 256;
+    const unsigned wpb = block / 64;
+    auto go = [&](auto ldc) -> int {
+      constexpr int LDC = decltype(ldc)::value;
+      const size_t sh = (size_t)wpb * RowImage<LDC>::BYTES;
+      hipLaunchKernelGGL((k_lvb_reverse_flat<22, LDC>), dim3((waves + wpb - 1) / wpb), dim3(block), sh,
+                         (hipStream_t)stream, a, pred, seed, offset, offset_dev, (float)last_class_div,
+                         exclude_last_prefix, out, ntok, 1.0f / (float)npos);
+      D3PM_LAUNCH_CHECK("k_lvb_reverse_flat");
+      return D3PM_OK;
+    };
+    return ld == 22 ? go(std::integral_constant<int, 22>{}) : go(std::integral_constant<int, 24>{});
+  }
   if (allow_tpl && !expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0) {
     // one token per lane
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, 1);

@@ -49,6 +49,39 @@ struct RowImage {
       stage[h] = *reinterpret_cast<const piece_t*>(rows + ((base + r) * RB + j * PB));
     }
   }
+  // The same for rows that are contiguous in memory over the whole wave (`first` = first byte of the wave's first
+  // row): piece h of a lane is byte (64 h + lane) PB of that block, whatever the row length -- no division.  Pieces
+  // past `limit` (byte offset of the last piece that exists) re-read that piece; `full` (uniform over the wave) says
+  // that every piece exists.
+  __device__ __forceinline__ void request_flat(const char* __restrict__ first, unsigned limit, int lane, bool full) {
+    if (full) {
+#pragma unroll
+      for (int h = 0; h < PIECES; ++h)
+        stage[h] = *reinterpret_cast<const piece_t*>(first + (unsigned)(h * 64 + lane) * PB);
+    } else {
+#pragma unroll
+      for (int h = 0; h < PIECES; ++h)
+        stage[h] = *reinterpret_cast<const piece_t*>(first + min((unsigned)(h * 64 + lane) * PB, limit));
+    }
+  }
+  // Image row of piece 64 h + lane, from the lane's own quotient and remainder by PIECES (taken once).
+  struct LaneSplit { unsigned row, col; };
+  __device__ static __forceinline__ LaneSplit split(int lane) {
+    return LaneSplit{(unsigned)lane / PIECES, (unsigned)lane % PIECES};
+  }
+  __device__ __forceinline__ void deposit_flat(char* img, int lane, LaneSplit ls) const {
+#pragma unroll
+    for (int h = 0; h < PIECES; ++h) {
+      const unsigned q = h * 64 + lane;
+      if constexpr (STRIDE == RB) {
+        *reinterpret_cast<piece_t*>(img + q * PB) = stage[h];
+      } else {
+        const unsigned QH = (64u * h) / PIECES, RH = (64u * h) % PIECES;   // constants once unrolled
+        const unsigned row = ls.row + QH + ((ls.col + RH >= (unsigned)PIECES) ? 1u : 0u);
+        *reinterpret_cast<piece_t*>(img + q * PB + row * (STRIDE - RB)) = stage[h];
+      }
+    }
+  }
   // The requested pieces into the image.
   __device__ __forceinline__ void deposit(char* img, int lane) const {
 #pragma unroll

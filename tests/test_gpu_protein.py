@@ -303,6 +303,42 @@ def test_reverse_step_device_noise_at_sampler_shape(pkg, tables500, n_tok):
             assert len({bytes(r) for r in out.cpu().numpy().astype(np.uint8)}) == Bn
 
 
+@pytest.mark.parametrize("n_tok", [22, 24])
+def test_reverse_step_device_noise_mixed_timesteps(pkg, tables500, n_tok):
+    """Sequences of 100 positions at three different timesteps: the flat token-per-lane kernel gives a wave 64
+    consecutive tokens of the batch, so most waves hold the end of one sequence and the start of the next, each with
+    its own timestep; per-timestep class frequencies against the oracle's marginal, and the MSA knobs by position."""
+    from d3pm_amd.protein_generation.generate import reverse_step
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    tb = protein_tables(Qt, Qb)
+    gen = torch.Generator().manual_seed(29 + n_tok)
+    Bn, Ln = 3 * 700, 100
+    ts = (400, 3, 250)
+    logits1 = torch.randn(1, n_tok, generator=gen) * 1.5
+    logits = logits1.expand(Bn, Ln, n_tok).contiguous().to(DEV)
+    x = torch.full((Bn, Ln), 7, device=DEV)
+    tt = torch.tensor(ts).repeat(Bn // 3).to(DEV)
+    c = torch.zeros(1, dtype=torch.int64, device=DEV)
+    out = reverse_step(tb, logits, x, tt, rng=(5, 0, c))
+    assert torch.equal(out, reverse_step(tb, logits, x, tt, rng=(5, 0, c)))
+    assert int(out.min()) >= 0 and int(out.max()) < 22
+    half = reverse_step(tb, logits, x, tt, rng=(6, 0, c), last_class_div=1.7, exclude_last_prefix=Ln // 2)
+    for i, t in enumerate(ts):
+        P = pr.reverse_marginal(logits1.expand(2, n_tok), torch.tensor([7, 7]), Qt.cpu()[t], Qb.cpu()[t - 1])[0].numpy()
+        part = out[i::3]
+        n = part.numel()
+        freq = torch.bincount(part.flatten().cpu(), minlength=22).numpy() / n
+        assert (np.abs(freq - P) < 5 * np.sqrt(P * (1 - P) / n) + 1e-5).all(), (t, freq, P)
+        for sl, w_last in ((half[i::3, :Ln // 2], 0.0), (half[i::3, Ln // 2:], 1.0 / 1.7)):
+            Pm = P.copy()
+            Pm[21] *= w_last
+            Pm /= Pm.sum()
+            n = sl.numel()
+            freq = torch.bincount(sl.flatten().cpu(), minlength=22).numpy() / n
+            assert (np.abs(freq - Pm) < 5 * np.sqrt(Pm * (1 - Pm) / n) + 1e-5).all(), (t, w_last, freq, Pm)
+
+
 @pytest.mark.timeout(600)
 def test_graphed_reverse_sampler_full_length(pkg, tables500):
     """The whole T = 500 loop (499 steps) of 1024 sequences of 263 positions as one HIP graph, as the sampling
