@@ -516,11 +516,11 @@ def worker(args):
                    "sequences": done, "seconds": rev_el,
                    "end_to_end_tiny_denoiser": done_e2e / e2e_el,
                    "roofline": {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_tpl<22, 22> via "
+                                "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_flat<22, 22> via "
                                 "d3pm_lvb_reverse_step, back-to-back launches between two HIP events",
                                 "kernel_ms": rk_ms, "algorithmic_bytes_per_token": rbytes,
                                 "tokens_per_launch": nb * SEQ_LEN,
-                                "traffic": measured_traffic("k_lvb_reverse_tpl")}}
+                                "traffic": measured_traffic("k_lvb_reverse_flat<22, 22>")}}
 
     # ---- secondary: the image configuration (B=128, 32x32x1, K=256, T=1000, Gaussian Q): dense contraction on
     # the matrix cores, fused loss fwd+bwd; priced against the dense float32 MFMA peak

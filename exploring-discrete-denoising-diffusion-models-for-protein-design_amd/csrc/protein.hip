@@ -335,11 +335,13 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   char* const myrow = img + lane * Img::STRIDE;
   Img rows;
   int x0 = 0, xt = 0;
+  const typename Img::LaneSplit ls = Img::split(lane);
   auto issue = [&](unsigned base) {
     const unsigned last = p1 - 1 - base, mine = min((unsigned)lane, last);
     x0 = (int)x0row[base + mine];
     xt = (int)xtrow[base + mine];
-    rows.request(prow, base, last, lane);
+    // the wave's rows are one contiguous block of the sequence
+    rows.request_flat(prow + (size_t)base * Img::RB, (last + 1) * Img::RB - Img::PB, lane, last >= 63);
   };
   unsigned base = pbeg + wave * 64;
   if (base < p1) issue(base);
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
 #pragma unroll
       for (int j = 0; j < LD; ++j) e[j] = 0.0f;
     } else {
-      rows.deposit(img, lane);
+      rows.deposit_flat(img, lane, ls);
       wave_lds_order();
       Img::read_row(img, lane, e);
       const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
@@ -443,6 +445,9 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         // far smaller.
         const float Dl = same_b ? -da * w1 : da * w2, cdn = -c3 * den;
         float qv[K], G1 = 0, Hq = 0, Hp = 0;
+        // (One logarithm for several classes of equal weight, as the image kernel takes it, does not carry over: a
+        // product of the ratios kept as 1 + D loses the factor's relative accuracy wherever a ratio is far below
+        // one (early timesteps), and kept as a plain product it is rounded against one (late timesteps).)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
           const float sp = fmaf(e2[j], c3, mo[j]);
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     *reinterpret_cast<float*>(myrow + 4 * x0) += add0;
     *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
     wave_lds_order();
-    Img::store(img, drow, base, p1 - base, lane);
+    Img::store_flat(img, drow + (size_t)base * Img::RB, min(64u, p1 - base), lane, ls);
     if (base + blockDim.x >= p1) break;
     wave_lds_order();
     issue(base + blockDim.x);

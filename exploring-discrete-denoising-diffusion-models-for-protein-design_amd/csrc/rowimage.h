@@ -108,6 +108,21 @@ struct RowImage {
         *reinterpret_cast<piece_t*>(img + lane * STRIDE + j * PB) = piece_t{z[2 * j], z[2 * j + 1]};
     }
   }
+  // The image's first `nrows` rows to a contiguous block of rows starting at `first`, addressed as in request_flat.
+  __device__ static __forceinline__ void store_flat(const char* img, char* __restrict__ first, unsigned nrows, int lane,
+                                                    LaneSplit ls) {
+#pragma unroll
+    for (int h = 0; h < PIECES; ++h) {
+      const unsigned q = h * 64 + lane;
+      unsigned at = q * PB;
+      if constexpr (STRIDE != RB) {
+        const unsigned QH = (64u * h) / PIECES, RH = (64u * h) % PIECES;   // constants once unrolled
+        at += (ls.row + QH + ((ls.col + RH >= (unsigned)PIECES) ? 1u : 0u)) * (STRIDE - RB);
+      }
+      const piece_t v = *reinterpret_cast<const piece_t*>(img + at);
+      if (q * PB < nrows * RB) __builtin_nontemporal_store(v, reinterpret_cast<piece_t*>(first + q * PB));
+    }
+  }
   // The image's first `nrows` rows to global memory, coalesced, non-temporal (a streamed output).
   __device__ static __forceinline__ void store(const char* img, char* __restrict__ rows, unsigned base, unsigned nrows,
                                                int lane) {
