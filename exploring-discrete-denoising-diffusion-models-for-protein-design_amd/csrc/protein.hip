@@ -83,6 +83,49 @@ __global__ __launch_bounds__(PBLOCK) void k_corrupt(ProtArgs a, const double* __
   }
 }
 
+// Forward corruption with noise drawn on the device and no probabilities asked for: one token per lane, float32.
+// Row x0 of a column-structured Qbar_t is off_j everywhere except diag_x0 at j = x0, so the draw is two-staged:
+//   x_t == x0 with probability diag_x0 / (sum_j off_j - off_x0 + diag_x0), decided on a 32-bit integer threshold that
+//   the workgroup's first wave forms in float64 (a step that moves one token in 10^5 keeps five digits of that
+//   probability);
+//   otherwise class j != x0 in proportion to off_j: inverse CDF over the prefix sums of off with x0's share taken
+//   out, one float32 uniform.
+// Both words come from one Philox2x32-10 call per token, keyed per launch as in k_lvb_reverse_flat.  Nothing here is
+// matched bit for bit by a host computation (the recorded-draw variant above is).
+__global__ __launch_bounds__(256) void k_corrupt_lane(ProtArgs a, uint64_t seed, uint64_t offset,
+                                                      int64_t* __restrict__ x_t) {
+  __shared__ float s_off[64], s_pre[64];
+  __shared__ uint32_t s_stay[64];
+  const int K = a.tb.K;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int t = clamp_index((int)a.t[b], a.tb.T);
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const double o = lane < K ? dgd(a.tb.qbar_digest, t, 1, K)[lane] : 0.0;
+    const double d = lane < K ? dgd(a.tb.qbar_digest, t, 0, K)[lane] : 0.0;
+    const double tot = wave_sum(o);
+    const double stay = d / (tot - o + d);                   // (lanes past K: 0 / 0, never read)
+    s_stay[lane] = stay >= 1.0 ? 0xffffffffu : (uint32_t)(stay * 4294967296.0);
+    s_off[lane] = (float)o;
+    s_pre[lane] = group_scan_inclusive<64>((float)o, lane);
+  }
+  __syncthreads();
+  const float tot_off = s_pre[K - 1];
+  const U4 pad = philox4x32_10(offset, 0x13198A2E03707344ull, seed);
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  for (long pos = chunk * a.chunk_pos + threadIdx.x; pos < p1; pos += blockDim.x) {
+    const long n = (long)b * a.npos + pos;
+    const int x0 = clamp_index((int)a.x0[n], K);
+    const U2 r = philox2x32_10((uint32_t)n ^ pad.x, (uint32_t)((uint64_t)n >> 32) ^ pad.y, pad.z);
+    const float off_x0 = s_off[x0];
+    const float target = u01_open(r.x) * (tot_off - off_x0);
+    const float target_hi = target + off_x0;                 // for the classes from x0 on
+    int cnt = 0;
+    for (int j = 0; j < K - 1; ++j) cnt += (s_pre[j] <= (j < x0 ? target : target_hi)) ? 1 : 0;
+    x_t[n] = r.y < s_stay[x0] ? x0 : cnt;
+  }
+}
+
 // ------------------------------------------------------------------ shared maths
 // 1/x in float64 from the hardware estimate and two Newton steps (error of the
 // order of 1e-16 relative, not correctly rounded; a third of the cost of a division).
@@ -965,6 +1008,13 @@ extern "C" int d3pm_corrupt(const d3pm_tables_f64* tb, const int64_t* x0, const 
   if (int rc = check_prot(tb, B, npos)) return rc;
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(x0 && t && x_t, "null pointer");
+  static const bool allow_lane = !(getenv("D3PM_CORRUPT_OLD") && atoi(getenv("D3PM_CORRUPT_OLD")));
+  if (allow_lane && !expo && !probs && tb->K <= 64) {
+    ProtArgs a = make_prot(tb, x0, nullptr, t, B, npos, 1);
+    hipLaunchKernelGGL(k_corrupt_lane, dim3(B * a.chunks), dim3(256), 0, (hipStream_t)stream, a, seed, offset, x_t);
+    D3PM_LAUNCH_CHECK("k_corrupt_lane");
+    return D3PM_OK;
+  }
   return dispatch_layout(tb->K, false, [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, x0, nullptr, t, B, npos, L::G);

@@ -67,14 +67,50 @@ def test_forward_corruption_golden(pkg, tables500):
     s, p = sample_transition_matrix(tok.one_hot(x0[2]), Qb[250], noise=T_(g["expo"][2]))
     np.testing.assert_array_equal(s.cpu().numpy(), g["x_t"][2])
     assert p.shape == (263, 22)
-    # Philox path: valid tokens, repeatable under a seed, right marginal at t = 499 (uniform)
+    # Philox path: valid tokens, repeatable under a seed, right marginal at t = 499
     torch.manual_seed(5); a, _ = corrupt_batch(tb, x0, ts.clamp(max=499))
     torch.manual_seed(5); b, _ = corrupt_batch(tb, x0, ts.clamp(max=499))
     assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < 22
     big = torch.zeros((64, 4096), dtype=torch.int64, device=DEV)
     xt, _ = corrupt_batch(tb, big, torch.full((64,), 499, device=DEV))
-    freq = torch.bincount(xt.flatten(), minlength=22).float() / xt.numel()
-    assert float((freq - 1 / 22).abs().max()) < 2e-3
+    freq = torch.bincount(xt.flatten(), minlength=22).double().cpu().numpy() / xt.numel()
+    P = Qb[499, 0].cpu().numpy()                       # nearly, not exactly, uniform: the start class keeps 0.0474
+    assert (np.abs(freq - P) < 5 * np.sqrt(P * (1 - P) / xt.numel())).all(), (freq, P)
+
+
+@pytest.mark.parametrize("want_probs", [False, True])
+def test_corrupt_device_noise_distribution(pkg, tables500, want_probs):
+    """Forward corruption with noise drawn on the device (token-per-lane kernel without probabilities, lane-group
+    kernel with them): class frequencies of x_t against row x0 of Qbar_t, at timesteps from 'hardly anything moves'
+    to the uniform end, a different timestep and start class per sequence."""
+    from scipy.stats import binom
+    from d3pm_amd.protein_generation.utils import corrupt_batch
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    tb = protein_tables(Qt, Qb)
+    ts = [0, 1, 5, 40, 150, 499]
+    Bn, Ln = len(ts) * 4, 50000
+    cls = torch.tensor([(3 * i + 1) % 22 for i in range(Bn)])
+    x0 = cls[:, None].expand(Bn, Ln).contiguous().to(DEV)
+    t = torch.tensor(ts).repeat_interleave(4).to(DEV)
+    torch.manual_seed(3)
+    xt, probs = corrupt_batch(tb, x0, t, want_probs=want_probs)
+    torch.manual_seed(3)
+    again, _ = corrupt_batch(tb, x0, t, want_probs=want_probs)
+    assert torch.equal(xt, again)
+    assert int(xt.min()) >= 0 and int(xt.max()) < 22
+    counts = torch.nn.functional.one_hot(xt.cpu(), 22).sum(dim=1).numpy()          # [B, K]
+    P = Qb.cpu()[t.cpu(), cls].numpy()                                               # [B, K]
+    if want_probs:
+        np.testing.assert_allclose(probs[:, 0].cpu().numpy(), P, rtol=1e-12, atol=1e-18)
+    tail = np.minimum(binom.cdf(counts, Ln, P), binom.sf(counts - 1, Ln, P))
+    assert tail.min() > 1e-7, (tail.min(), np.unravel_index(tail.argmin(), tail.shape))
+    # pooled over the four sequences of a timestep: the share of moved tokens
+    for i, tt in enumerate(ts):
+        rows = slice(4 * i, 4 * i + 4)
+        moved = float((xt[rows] != x0[rows]).double().mean())
+        expect = float(np.mean([1 - P[r, cls[r]] for r in range(4 * i, 4 * i + 4)]))
+        assert abs(moved - expect) < 6 * np.sqrt(expect * (1 - expect) / (4 * Ln)) + 1e-7, (tt, moved, expect)
 
 
 @pytest.mark.parametrize("n_tok", [22, 24])
