@@ -78,6 +78,11 @@ def main():
             timed("hybrid_fwd", lambda: hybrid(False), (4 * K + 16) * B * L, "d3pm_hybrid_loss forward only, 4K+16 B/token")
             timed("q_sample", lambda: d.q_sample(x0, t), 16 * B * L,
                   "q_sample with device noise (facade call), 16 B/token")
+            t_out = torch.empty(B, dtype=torch.int32, device=dev)
+            xt_out = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
+            timed("q_sample_draw_t", lambda: check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), 8, B, L, 1, 0, None, None,
+                                                                             ptr(t_out), ptr(xt_out), sp)),
+                  16 * B * L, "d3pm_q_sample_draw_t (timestep draw + corruption, device noise), 16 B/token")
 
     # ---- protein-style: B=256, L=512, K=22, n_tokens=24; reverse step at 1250 x 263, n_tokens=22
     tok = d3pm_amd.Tokenizer()
