@@ -285,9 +285,12 @@ def worker(args):
     # graph + K % n replays of the one-step graph
     spg = args.steps_per_graph if not (args.compat or args.no_graph) else 1
 
+    pipelined = spg > 1 and not args.no_pipeline
+
     def make_runner(dd, seed):
         one = make_step(dd, args.compat, not args.no_graph)
-        multi = (d3pm_amd.graphs.GraphedTrainingStep(dd, model_fn, x0, seed=seed, params=[logits], steps=spg).replay
+        multi = (d3pm_amd.graphs.GraphedTrainingStep(dd, model_fn, x0, seed=seed, params=[logits], steps=spg,
+                                                     pipelined=pipelined).replay
                  if spg > 1 else None)
 
         def run_steps(k):
@@ -300,6 +303,9 @@ def worker(args):
         return run_steps, one
 
     run_steps, step = make_runner(d, 4321 + rank)
+    # for the record: the same n-step graph with two launches per step (captured here: before the process group)
+    plain_multi = (d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=99 + rank, params=[logits], steps=spg).replay
+                   if pipelined and not args.no_secondary else None)
     other = make_step(d, not args.compat, not args.no_graph) if not args.no_secondary else None
     d_abs = run_abs = None
     if not args.no_secondary and rank == 0:
@@ -395,6 +401,16 @@ def worker(args):
             step()
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - s0) * 5.0
+    plain_ms = None
+    if plain_multi is not None:     # two launches per step, same number of steps per graph
+        for _ in range(10):
+            plain_multi()
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(50):
+            plain_multi()
+        torch.cuda.synchronize()
+        plain_ms = (time.perf_counter() - s0) / (50 * spg) * 1e3
     other_ms = None
     if other is not None:           # the other call shape, for the record (same graph/eager mode, 100 steps)
         for _ in range(10):
@@ -420,7 +436,7 @@ def worker(args):
 
     # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
     # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
-    def fused_kernel_ms(dd, nsets=1):
+    def fused_kernel_ms(dd, nsets=1, with_next=False):
         """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
         launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
         tb = dd.tables()
@@ -441,11 +457,23 @@ def worker(args):
             check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
                                        LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
                                        None, 0, ptr(ws), wsb, sp))
-        return event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10)
+        if not with_next:
+            return event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10)
+        t_n = torch.empty(B, dtype=torch.int32, device=dev)
+        xt_n = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
+
+        def fused_with_next():
+            x0_i, xt_i, lg_i, dl_i = sets[0]
+            check(lib.d3pm_hybrid_loss_then_q_sample(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
+                                                     LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s),
+                                                     ptr(dl_i), ptr(ws), wsb, ptr(x0_i), 8, 7, 0, None, ptr(t_n),
+                                                     ptr(xt_n), sp))
+        return event_ms(fused_with_next, max(args.steps, 200), warm=12)
 
     progress("fused kernel back to back")
     kern_ms = fused_kernel_ms(d)
     kern_rot_ms = None if args.no_secondary else fused_kernel_ms(d, nsets=10)
+    kern_next_ms = fused_kernel_ms(d, with_next=True) if pipelined else None
 
     progress("absorbing")
     absorbing = None
@@ -604,6 +632,11 @@ def worker(args):
                 "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
                         "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "
                         "i.e. served from HBM"}
+        if kern_next_ms:
+            # the launch the pipelined step actually makes: the same kernel carrying the next batch's timestep draw
+            # and corruption (k_hybrid_loss_pair32<true, true>): 16 more bytes per token
+            roof["kernel_ms_with_next_q_sample"] = kern_next_ms
+            roof["frac_with_next_q_sample"] = (BYTES_PER_TOKEN + 16) * B * L / (kern_next_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if kern_rot_ms:
             roof["kernel_ms_rotating_buffers"] = kern_rot_ms
             roof["frac_rotating_buffers"] = BYTES_PER_TOKEN * B * L / (kern_rot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -615,7 +648,12 @@ def worker(args):
                                    "q_sample (Philox) + fused posterior/hybrid-loss fwd+bwd to per-example losses and dlogits (of the batch mean), "
                                    "denoiser excluded",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"batch-sharded x{world}, no collective",
-                       "launch": "eager" if args.no_graph else f"hip-graph replay, {spg} step(s) per graph",
+                       "launch": "eager" if args.no_graph else (
+                           f"hip-graph replay, {spg} step(s) per graph" + (
+                               f", software-pipelined: the loss launch of step i also draws the timesteps and noisy tokens "
+                               f"of step i+1 (d3pm_hybrid_loss_then_q_sample), {spg + 1} launches per {spg} steps; every step "
+                               "still does one timestep draw, one corruption and one loss fwd+bwd" if pipelined else "")),
+                       "two_launches_per_step_ms_per_step": plain_ms,
                        "timed_steps": n_timed, "timed_repeats_of_steps": reps, "timed_seconds": elapsed,
                        "one_step_per_graph_ms_per_step": single_ms,
                        "calls": "training_losses(...).mean().backward()" if args.compat else "training_step(...)",
@@ -652,6 +690,9 @@ def main(argv=None):
     ap.add_argument("--steps-per-graph", type=int, default=8,
                     help="consecutive steps captured in one HIP graph (a graph launch costs ~19 us of host time: with one "
                          "step per graph the host, not the GPU, bounds the step rate)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="two launches per step (corruption, loss) instead of the loss launch of step i carrying the "
+                         "corruption of step i+1")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (reverse sampling, K=256 image configuration, protein-style loss, "

@@ -53,6 +53,8 @@ SIGNATURES = {
     "d3pm_q_sample_draw_t": (_I, [_T32, _P, _I, _I, _L, _U64, _U64, _P, _P, _P, _P, _P]),
     "d3pm_hybrid_loss": (_I, [_T32, _P, _L, _P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _U64,
                               _P, _SZ, _P]),
+    "d3pm_hybrid_loss_then_q_sample": (_I, [_T32, _P, _L, _P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P,
+                                            _SZ, _P, _I, _U64, _U64, _P, _P, _P, _P]),
     "d3pm_hybrid_loss_static": (_I, [_T32, _P, _L, _P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P,
                                      _U64, _P]),
     "d3pm_scale_rows": (_I, [_P, _P, _F, _I, _L, _P]),

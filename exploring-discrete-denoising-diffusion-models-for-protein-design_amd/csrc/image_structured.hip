@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace d3pm {
 
@@ -107,10 +108,134 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
 // ------------------------------------------------------------------ q_sample, device noise, structured tables
 // The reference samples x_t by Gumbel-max over softmax(log(q + eps)), i.e. from
 // weights w_j = q(x_t = j | x0) + eps.  With column structure those weights are
-// off_j + eps for every j except x0, so with noise drawn on the device one
-// uniform per token suffices: inverse CDF over the prefix sums of (off + eps),
-// kept in LDS per workgroup (one timestep), with the x0 entry spliced in.  One
-// thread per token, 16 bytes of traffic per token.
+// off_j + eps for every j except x0, where the weight is diag_x0 + eps.  With noise
+// drawn on the device the draw has two stages, from the two words of one
+// Philox2x32-10 call per token:
+//   x_t == x0 with probability (diag_x0 + eps) / (sum_j w_j), decided on a 32-bit
+//   integer threshold formed in float64 once per timestep (a step that moves one
+//   token in 10^5 keeps five digits of that probability);
+//   otherwise class j != x0 in proportion to off_j + eps: inverse CDF over the
+//   prefix sums of (off + eps), kept in LDS per workgroup, with x0's share taken
+//   out of the target; binary search, float32.
+// One thread per token, 16 bytes of traffic per token.  The per-launch key of the
+// token stream is a Philox4x32-10 call on (offset, seed), which the scalar unit
+// evaluates.  QsTables is the per-timestep part; a workgroup's first wave builds it.
+template <int KMAX>
+struct QsTablesT {
+  float cdf[KMAX + 1];   // cdf[j] = sum_{i<j} (off_i + eps)
+  float w[KMAX];         // off_j + eps
+  uint32_t stay[KMAX];   // 2^32 * P(x_t == x0 = j)
+};
+typedef QsTablesT<256> QsTables;
+
+// Built by the 64 lanes of one wave (lane = 0..63) in two steps, so that a caller can put other requests between
+// the digest loads and their use; the caller puts a workgroup barrier between qs_finish and qs_draw.
+struct QsRows { float o[4], d[4]; };
+__device__ __forceinline__ QsRows qs_fetch(const float* __restrict__ digest, int t, int K, int lane) {
+  const float* dgd_ = dg(digest, t, 0, K);
+  const float* dgo_ = dg(digest, t, 1, K);
+  QsRows r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * lane + i;
+    r.o[i] = j < K ? dgo_[j] : 0.0f;
+    r.d[i] = j < K ? dgd_[j] : 0.0f;
+  }
+  return r;
+}
+// The same rows through the scalar unit (K a compile-time multiple of 4, at most 64): the 2 K values arrive in scalar
+// registers over the scalar cache's own path to L2 -- not behind whatever the compute unit's vector memory pipeline has
+// queued -- and are dealt to the lanes with one v_writelane each.  The digests are written once at set-up, long before
+// this launch: reading them through the constant address space is sound.
+template <int LANE>
+__device__ __forceinline__ void qs_writelane(int& dst, int val) {      // (the lane select has to be a literal: one
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(val), "n"(LANE)); // scalar register per instruction)
+}
+template <int KC, size_t... Js>
+__device__ __forceinline__ void qs_deal(int (&dst)[4], const int (&val)[KC], std::index_sequence<Js...>) {
+  (qs_writelane<(int)(Js / 4)>(dst[Js % 4], val[Js]), ...);
+}
+template <int KC>
+__device__ __forceinline__ QsRows qs_fetch_scalar(const float* __restrict__ digest, int t) {
+  typedef const int __attribute__((address_space(4))) cint;
+  cint* dd = (cint*)(uintptr_t)dg(digest, t, 0, KC);
+  cint* oo = (cint*)(uintptr_t)dg(digest, t, 1, KC);
+  int o[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+  int ov[KC], dv[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) { ov[j] = oo[j]; dv[j] = dd[j]; }     // (all requests before the first use)
+  qs_deal(o, ov, std::make_index_sequence<KC>{});
+  qs_deal(d, dv, std::make_index_sequence<KC>{});
+  QsRows r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r.o[i] = __builtin_bit_cast(float, o[i]); r.d[i] = __builtin_bit_cast(float, d[i]); }
+  return r;
+}
+template <class Tables>
+__device__ __forceinline__ void qs_finish(Tables& q, const QsRows& r, int K, float eps, int lane) {
+#pragma clang fp contract(off)      // the same roundings in every kernel this is inlined into
+  float w[4], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = 4 * lane + i < K ? r.o[i] + eps : 0.0f;
+    s += w[i];
+  }
+  // Up to 64 classes sit on the first 16 lanes: the scan stays inside a DPP row.  (The wider scan gives these lanes
+  // the same sums bit for bit -- its steps of 16 and 32 add nothing to them -- and its last lane the value of lane 15.)
+  float incl, tot;
+  if (K <= 64) {
+    incl = group_scan_inclusive<16>(s, lane & 15);
+    tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 15));
+  } else {
+    incl = group_scan_inclusive<64>(s, lane);
+    tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+  }
+  const double total = (double)tot;
+  float run = incl - s;
+  if (lane == 0) q.cdf[0] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * lane + i;
+    run += w[i];
+    if (j < K) {
+      q.cdf[j + 1] = run;
+      q.w[j] = w[i];
+      const double d = (double)(r.d[i] + eps);
+      const double stay = d / (total - (double)w[i] + d);
+      q.stay[j] = stay >= 1.0 ? 0xffffffffu : (uint32_t)(stay * 4294967296.0);
+    }
+  }
+}
+
+struct QsKey { uint32_t x, y, z; };
+__device__ __forceinline__ QsKey qs_key(uint64_t offset, uint64_t seed) {
+  // (the offset may have come through a vector load: say that it is uniform, so that the scalar unit does this)
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)offset);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(offset >> 32));
+  const U4 pad = philox4x32_10(((uint64_t)hi << 32) | lo, 0xA4093822299F31D0ull, seed);
+  return QsKey{pad.x, pad.y, pad.z};
+}
+
+// x_t of token n (global index) whose clean class is x0.
+template <class Tables>
+__device__ __forceinline__ int qs_draw(const Tables& q, int K, int x0, uint64_t n, QsKey key) {
+#pragma clang fp contract(off)      // the same roundings in every kernel this is inlined into
+  const U2 r = philox2x32_10((uint32_t)n ^ key.x, (uint32_t)(n >> 32) ^ key.y, key.z);
+  if (r.y < q.stay[x0]) return x0;
+  const float lo = q.cdf[x0], wx = q.w[x0];
+  const float target = u01_open(r.x) * (q.cdf[K] - wx);      // over the other classes
+  const float rr = target < lo ? target : target + wx;
+  // largest j with cdf[j] <= rr, j in [0, K-1]
+  int l = 0, h = K;            // invariant: cdf[l] <= rr < cdf[h] (up to rounding at the ends)
+  while (h - l > 1) {
+    const int mid = (l + h) >> 1;
+    if (q.cdf[mid] <= rr) l = mid; else h = mid;
+  }
+  // rounding at the splice can land on x0's own slot: move to the side the target came from
+  if (l == x0) l = (target < lo) ? (x0 > 0 ? x0 - 1 : (K > 1 ? 1 : 0)) : (x0 + 1 < K ? x0 + 1 : (K > 1 ? K - 2 : 0));
+  return l;
+}
+
 // With `t_draw` the timestep of each batch element is drawn here as well,
 // uniform on [0, T) from the same Philox key (counter 2^63 + b, disjoint from the
 // token counters), and written to t_draw[b] for the denoiser and the loss.
@@ -124,16 +249,13 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
                                                          int32_t* __restrict__ t_draw, float* __restrict__ clear,
                                                          int64_t* __restrict__ out) {
   if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0.0f;
-  __shared__ float cdf[257];     // cdf[j] = sum_{i<j} (off_i + eps)
-  __shared__ float dmo[256];     // diag_j - off_j
+  __shared__ QsTables q;
   const int K = a.tb.K;
-  const float eps = a.tb.eps;
   if (offset_dev) offset += *offset_dev;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   const long pfirst = chunk * a.chunk_pos + threadIdx.x;
-  // the first token's load is in flight, and its random words are computed, while the
-  // timestep -> digest -> prefix-sum chain runs
+  // the first token's load is in flight while the timestep -> digest -> prefix-sum chain runs
   int x0_next = 0;
   if (pfirst < p1) x0_next = load_index(a.x0, (long)b * a.npos + pfirst, a.x0_bytes, a.tb.K);
   int t;
@@ -143,66 +265,14 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
   } else {
     t = load_index(a.t, b, a.t_bytes, a.tb.T);
   }
-  const float* dgd_ = dg(a.tb.qbar_digest, t, 0, K);
-  const float* dgo_ = dg(a.tb.qbar_digest, t, 1, K);
-  if (threadIdx.x < 64) {        // one wave scans K <= 256 weights, four per lane
-    const int l = threadIdx.x;
-    float w[4], s = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * l + i;
-      w[i] = j < K ? dgo_[j] + eps : 0.0f;
-      s += w[i];
-    }
-    const float incl = group_scan_inclusive<64>(s, l);
-    float run = incl - s;
-    if (l == 0) cdf[0] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * l + i;
-      run += w[i];
-      if (j < K) cdf[j + 1] = run;
-    }
-  }
-  float dmo_mine[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = threadIdx.x + i * BLOCK;
-    dmo_mine[i] = j < K ? dgd_[j] - dgo_[j] : 0.0f;
-  }
-  U4 r_next = philox4x32_10((uint64_t)((long)b * a.npos + pfirst), offset, seed);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (threadIdx.x + i * BLOCK < K) dmo[threadIdx.x + i * BLOCK] = dmo_mine[i];
+  if (threadIdx.x < 64) qs_finish(q, qs_fetch(a.tb.qbar_digest, t, K, threadIdx.x), K, a.tb.eps, threadIdx.x);
+  const QsKey key = qs_key(offset, seed);
   __syncthreads();
-  const float total = cdf[K];
   for (long pos = pfirst; pos < p1; pos += blockDim.x) {
     const long n = (long)b * a.npos + pos;
     const int x0 = x0_next;
-    const U4 r4 = r_next;
-    if (pos + blockDim.x < p1) {
-      x0_next = load_index(a.x0, n + blockDim.x, a.x0_bytes, a.tb.K);
-      r_next = philox4x32_10((uint64_t)(n + blockDim.x), offset, seed);
-    }
-    const float extra = dmo[x0];
-    const double r = u01d_open(r4.x, r4.y) * ((double)total + (double)extra);
-    const double lo = cdf[x0], hi = (double)cdf[x0 + 1] + (double)extra;
-    int j;
-    if (r >= lo && r < hi) {
-      j = x0;
-    } else {
-      const float rr = (float)(r < lo ? r : r - (double)extra);
-      // largest j with cdf[j] <= rr, j in [0, K-1]
-      int l = 0, h = K;          // invariant: cdf[l] <= rr < cdf[h] (up to rounding at the ends)
-      while (h - l > 1) {
-        const int mid = (l + h) >> 1;
-        if (cdf[mid] <= rr) l = mid; else h = mid;
-      }
-      j = l;
-      // rounding at the splice can land on x0's generic slot: move to the side r came from
-      if (j == x0) j = (r < lo) ? (x0 > 0 ? x0 - 1 : x0) : (x0 + 1 < K ? x0 + 1 : x0);
-    }
-    out[n] = j;
+    if (pos + blockDim.x < p1) x0_next = load_index(a.x0, n + blockDim.x, a.x0_bytes, a.tb.K);
+    out[n] = qs_draw(q, K, x0, (uint64_t)n, key);
   }
 }
 
@@ -965,10 +1035,21 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
 // over the chip.  The price: the per-token scalar work runs on both lanes, the per-class constants are per lane
 // (vector registers) and four sums per token cross the pair (one DPP operation each).  The LDS image holds the
 // wave's 64 half-rows at a stride of 80 bytes (odd multiple of 16).
-template <bool GRAD>
+// NEXT: the launch also draws the timesteps and the noisy tokens of the NEXT batch (what d3pm_q_sample_draw_t
+// does, same Philox stream, same result) while its own rows are still on their way from memory: a training loop
+// whose batches are staged ahead then needs one launch per step instead of two.  The first wave builds the
+// per-timestep tables of the batch element's next timestep; its digest loads go out before its row loads, so they
+// do not queue behind them.
+struct NextQ {
+  const void* x0; int x0_bytes;                // clean tokens of the next batch, [B, npos]
+  uint64_t seed, offset; const uint64_t* offset_dev;
+  int32_t* t_out; int64_t* x_t;                // [B] and [B, npos]
+};
+
+template <bool GRAD, bool NEXT = false>
 __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float per_pos_bits) {
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float per_pos_bits, NextQ nx) {
   // per_pos_bits = 1 / (npos ln 2), formed on the host: the kernel runs its set-up once per wave of 32 tokens
   constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
   extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
@@ -1017,6 +1098,40 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   };
   unsigned base = wave * 32;
   const int t = load_index(a.t, b, a.t_bytes, a.tb.T);      // requested first: loads retire in issue order
+  __shared__ QsTablesT<KC> s_next[NEXT ? PW : 1];
+  // The next batch's share of this launch, on the LAST threads of the workgroup (token blockDim.x - 1 - threadIdx.x;
+  // the host launches this variant for npos <= blockDim.x).  A wave that holds such tokens does all of it on its own,
+  // BEFORE it asks for its rows: token load, timestep draw (scalar unit), digest rows of that timestep (scalar loads),
+  // per-timestep tables into the wave's own LDS copy, draw, store.  Rows are served in wave order and the vector
+  // units work through a SIMD's waves in that order too, so these waves' rows would have waited for the arithmetic
+  // of the earlier waves anyway; the waves without tokens run exactly the code of the plain kernel, and there is no
+  // workgroup barrier.
+  if constexpr (NEXT) {
+    const unsigned ntok = blockDim.x - 1 - threadIdx.x;
+    if (blockDim.x - 64u * (unsigned)(wave + 1) < p1) {       // (uniform over the wave)
+      __builtin_amdgcn_s_setprio(3);            // ahead of the other waves' arithmetic: this wave's rows wait on it
+      const unsigned nsh = nx.x0_bytes == 8 ? 3 : 2;          // the low dword of a token, either width
+      uint64_t noff = nx.offset;
+      if (nx.offset_dev) {
+        // a scalar load (the counter is written by earlier launches only)
+        uint64_t c;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(nx.offset_dev));
+        noff += c;
+      }
+      // requested here, used after the tables are built (no branch around the load: the compiler would put the
+      // clamp, and with it the wait, inside the branch)
+      const int tok = *reinterpret_cast<const int*>((const char*)nx.x0 + (((size_t)b * a.npos + min(ntok, p1 - 1)) << nsh));
+      const int tn = draw_timestep(b, a.tb.T, noff, nx.seed);
+      if (ntok == 0) nx.t_out[b] = tn;
+      qs_finish(s_next[wave], qs_fetch_scalar<KC>(a.tb.qbar_digest, tn), KC, eps, lane);
+      const QsKey key = qs_key(noff, nx.seed);
+      wave_lds_fence();
+      const uint64_t n = (uint64_t)b * (uint64_t)a.npos + ntok;
+      if (ntok < p1) nx.x_t[n] = qs_draw(s_next[wave], KC, clamp_index(tok, KC), n, key);
+      D3PM_TL(7);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
   if (base < p1) issue(base);
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
@@ -1572,13 +1687,15 @@ extern "C" size_t d3pm_hybrid_loss_workspace(int B, long npos, int K) {
 static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
                                   const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
                                   int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, LossOut o,
-                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s);
+                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s,
+                                  const struct NextQ* next_q, bool* next_done);
 
-extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
-                                const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
-                                int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, float* vb,
-                                float* ce, float* loss, float* dlogits, float* loss_mean, uint64_t* rng_counter,
-                                uint64_t rng_step, void* workspace, size_t workspace_bytes, void* stream) {
+static int hybrid_loss_impl(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
+                            const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
+                            int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, float* vb,
+                            float* ce, float* loss, float* dlogits, float* loss_mean, uint64_t* rng_counter,
+                            uint64_t rng_step, void* workspace, size_t workspace_bytes, void* stream,
+                            const NextQ* next_q, bool* next_done) {
   if (int rc = check_common(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(bytes_ok(tok_bytes) && bytes_ok(xt_bytes) && bytes_ok(t_bytes),
                  "token/timestep width must be 4 or 8 bytes");
@@ -1600,9 +1717,44 @@ extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, 
                            grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
   } else {
     rc = structured_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
-                                hybrid_coeff, grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s);
+                                hybrid_coeff, grad_scale, grad_out, o, dlogits, workspace, workspace_bytes, s, next_q,
+                                next_done);
   }
   return rc;
+}
+
+extern "C" int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
+                                const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
+                                int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, float* vb,
+                                float* ce, float* loss, float* dlogits, float* loss_mean, uint64_t* rng_counter,
+                                uint64_t rng_step, void* workspace, size_t workspace_bytes, void* stream) {
+  bool unused = false;
+  return hybrid_loss_impl(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type, hybrid_coeff,
+                          grad_scale, grad_out, vb, ce, loss, dlogits, loss_mean, rng_counter, rng_step, workspace,
+                          workspace_bytes, stream, nullptr, &unused);
+}
+
+extern "C" int d3pm_hybrid_loss_then_q_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0,
+                                              int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
+                                              int B, long npos, int loss_type, float hybrid_coeff, float grad_scale,
+                                              const float* grad_out, float* vb, float* ce, float* loss, float* dlogits,
+                                              void* workspace, size_t workspace_bytes, const void* next_x0,
+                                              int next_tok_bytes, uint64_t seed, uint64_t offset,
+                                              const uint64_t* offset_dev, int32_t* next_t_out, int64_t* next_x_t,
+                                              void* stream) {
+  D3PM_CHECK_ARG(bytes_ok(next_tok_bytes), "token width must be 4 or 8 bytes");
+  D3PM_CHECK_ARG(B == 0 || (next_x0 && next_t_out && (next_x_t || npos == 0)), "null pointer (next batch)");
+  D3PM_CHECK_ARG(B == 0 || ((const void*)next_x_t != x_t && (const void*)next_t_out != t),
+                 "the next batch's x_t / t must not be this step's x_t / t: the loss reads those while these are written");
+  NextQ nq{next_x0, next_tok_bytes, seed, offset, offset_dev, next_t_out, next_x_t};
+  bool fused = false;
+  const int rc = hybrid_loss_impl(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
+                                  hybrid_coeff, grad_scale, grad_out, vb, ce, loss, dlogits, nullptr, nullptr, 0,
+                                  workspace, workspace_bytes, stream, &nq, &fused);
+  if (rc || fused || B == 0) return rc;
+  // shapes the fused kernel does not take: the same two results from two launches
+  return d3pm_q_sample_draw_t(tb, next_x0, next_tok_bytes, B, npos, seed, offset, offset_dev, nullptr, next_t_out,
+                              next_x_t, stream);
 }
 
 // ------------------------------------------------------------------ the entry point that allocates nothing
@@ -1655,7 +1807,8 @@ extern "C" int d3pm_hybrid_loss_static(const d3pm_tables_f32* tb, const float* l
 static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0, int tok_bytes,
                                   const void* x_t, int xt_bytes, const void* t, int t_bytes, int B, long npos,
                                   int loss_type, float hybrid_coeff, float grad_scale, const float* grad_out, LossOut o,
-                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                                  float* dlogits, void* workspace, size_t workspace_bytes, hipStream_t s,
+                                  const struct NextQ* next_q, bool* next_done) {
   float* partials = (float*)workspace;
   const size_t partial_bytes = workspace_bytes;
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits));
@@ -1687,18 +1840,22 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       const long waves = (npos + 31) / 32;
       const int pblock = (int)(waves > 16 ? 16 : waves) * 64;
       const size_t sh = (size_t)(pblock / 64) * 64 * 80;
-      auto go = [&](auto grad) -> int {
-        auto kern = k_hybrid_loss_pair32<decltype(grad)::value>;
+      auto go = [&](auto grad, auto next) -> int {
+        auto kern = k_hybrid_loss_pair32<decltype(grad)::value, decltype(next)::value>;
         if (sh > 48 * 1024) {
           hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
           if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         }
         hipLaunchKernelGGL(kern, dim3(B), dim3(pblock), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale, grad_out,
-                           o, dlogits, (float)(1.0 / ((double)npos * 0.6931471805599453)));
+                           o, dlogits, (float)(1.0 / ((double)npos * 0.6931471805599453)), next_q ? *next_q : NextQ{});
         D3PM_LAUNCH_CHECK("k_hybrid_loss_pair32");
         return D3PM_OK;
       };
-      return dlogits ? go(std::true_type{}) : go(std::false_type{});
+      if (next_q && dlogits && npos <= pblock) {      // the launch that also corrupts the next batch
+        *next_done = true;
+        return go(std::true_type{}, std::true_type{});
+      }
+      return dlogits ? go(std::true_type{}, std::false_type{}) : go(std::false_type{}, std::false_type{});
     }
     auto launch_t = [&](auto kc, auto grad, auto maxt) -> int {
       constexpr int KC = decltype(kc)::value;

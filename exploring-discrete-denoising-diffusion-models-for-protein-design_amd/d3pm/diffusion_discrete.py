@@ -542,13 +542,20 @@ class DiscreteDiffusion:
         with torch.cuda.device(dev):
             check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(mean),
                                            ptr(t), ptr(x_t), stream_ptr()))
-        return {"t": t, "x_t": x_t, "mean": mean, "counter": counter}
+        return {"t": t, "x_t": x_t, "mean": mean, "counter": counter, "seed": seed}
 
-    def loss_step(self, model_fn, *, x_start, corrupted, backward=True, advance=4):
+    def loss_step(self, model_fn, *, x_start, corrupted, backward=True, advance=4, prefetch=None):
         """Second half of ``training_step``: the denoiser, then one launch for the
         per-example losses and d mean / d logits, handed to autograd.  ``advance``:
         what the loss kernel adds to the Philox counter of ``corrupt_step`` (4 = one
-        step; a pipelined sequence of n steps passes 0 for all but the last, 4 n there)."""
+        step; a pipelined sequence of n steps passes 0 for all but the last, 4 n there).
+
+        ``prefetch={'x_start': next batch, 'offset': its stream offset}``: the same
+        launch also does ``corrupt_step`` for the NEXT batch (same Philox stream, same
+        result as ``corrupt_step(x_start=next, rng=..., offset=...)``) while the loss's
+        rows are on their way from memory; the result dict then carries it under
+        ``'next'``, ready to be the ``corrupted`` of the following ``loss_step``.  The
+        counter is only read by such a launch (``advance`` must be 0)."""
         x0 = _as_tokens(x_start)
         tb = self.tables()
         B, npos = self._dims(x0)
@@ -564,12 +571,33 @@ class DiscreteDiffusion:
         dl = torch.empty_like(lg) if want_grad else None
         ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        nxt = None
+        if prefetch is not None:
+            assert mean is None and (counter is None or int(advance) == 0), \
+                "a launch that corrupts the next batch only reads the counter and keeps no device mean"
+            nx0 = _as_tokens(prefetch["x_start"])
+            _lib.require_device(nx0)
+            assert nx0.shape == x0.shape, (nx0.shape, x0.shape)
+            if counter is not None:
+                seed, off = int(corrupted["seed"]), int(prefetch.get("offset", 0))
+            else:
+                seed, off = _philox_ticket(dev)
+            nxt = {"t": torch.empty(B, dtype=torch.int32, device=dev),
+                   "x_t": torch.empty(x0.shape, dtype=torch.int64, device=dev), "mean": None, "counter": counter,
+                   "seed": seed}
         with torch.cuda.device(dev):
-            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
-                                       _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0),
-                                       float(np.float32(1.0) / np.float32(max(B, 1))), None, None, None, ptr(losses),
-                                       ptr(dl), ptr(mean), ptr(counter), int(advance) if counter is not None else 0,
-                                       ptr(ws), ws_bytes, stream_ptr()))
+            scale = float(np.float32(1.0) / np.float32(max(B, 1)))
+            if nxt is None:
+                check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
+                                           _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0), scale, None, None,
+                                           None, ptr(losses), ptr(dl), ptr(mean), ptr(counter),
+                                           int(advance) if counter is not None else 0, ptr(ws), ws_bytes, stream_ptr()))
+            else:
+                check(lib.d3pm_hybrid_loss_then_q_sample(
+                    tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
+                    _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0), scale, None, None, None, ptr(losses),
+                    ptr(dl), ptr(ws), ws_bytes, ptr(nx0), tok_bytes(nx0), seed, off, ptr(counter), ptr(nxt["t"]),
+                    ptr(nxt["x_t"]), stream_ptr()))
         if want_grad:
             holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
             del dl
@@ -577,6 +605,8 @@ class DiscreteDiffusion:
         out = StepResult(losses=losses, t=t, x_t=x_t)
         if mean is not None:
             out["loss"] = mean
+        if nxt is not None:
+            out["next"] = nxt
         return out
 
     def _unit(self, dev):

@@ -77,14 +77,22 @@ class GraphedTrainingStep:
     captured step, so after a replay they hold the last step's gradient --
     capture the optimiser inside ``model_fn``'s backward hooks or use ``steps=1``
     when every step's gradient is consumed on the host side.  ``outs`` lists the
-    result dict of every captured step, ``out`` is the last."""
+    result dict of every captured step, ``out`` is the last.
 
-    def __init__(self, diffusion, model_fn, x_start, seed: int = 0, warmup: int = 3, params=(), steps: int = 1):
+    ``pipelined`` (with ``steps`` > 1): the loss launch of step i also draws the
+    timesteps and noisy tokens of step i + 1 (``loss_step(prefetch=...)``), so a graph
+    of n steps holds n + 1 launches of the path instead of 2 n; timesteps, tokens,
+    losses and gradients are those of the unpipelined graph with the same seed, bit
+    for bit."""
+
+    def __init__(self, diffusion, model_fn, x_start, seed: int = 0, warmup: int = 3, params=(), steps: int = 1,
+                 pipelined: bool = False):
         self.diffusion, self.model_fn = diffusion, model_fn
         self.batches = list(x_start) if isinstance(x_start, (list, tuple)) else [x_start] * steps
         assert len(self.batches) == steps >= 1
         self.x_start = self.batches[0]
         self.seed, self.steps = int(seed), steps
+        self.pipelined = bool(pipelined) and steps > 1
         dev = self.x_start.device
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self._tables = diffusion.tables()                    # pinned: the graph holds raw pointers into the digests
@@ -93,19 +101,42 @@ class GraphedTrainingStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._body(self.x_start)
+                if self.pipelined:
+                    self._pipeline(params)
+                else:
+                    self._body(self.x_start)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         self.outs = []
         with torch.cuda.graph(self.graph):
-            for x in self.batches:
-                for p in params:
-                    p.grad = None
-                self.outs.append(self._body(x))
+            if self.pipelined:
+                self.outs = self._pipeline(params)
+            else:
+                for x in self.batches:
+                    for p in params:
+                        p.grad = None
+                    self.outs.append(self._body(x))
         self.out = self.outs[-1]
 
     def _body(self, x):
         return self.diffusion.training_step(self.model_fn, x_start=x, rng=(self.seed, self.counter))
+
+    def _pipeline(self, params):
+        """n steps as one corruption launch and n loss launches: step i's loss launch corrupts batch i + 1 at stream
+        offset 4 (i + 1) + counter (what step i + 1 of the unpipelined sequence reads after i + 1 advances of 4);
+        the last loss launch advances the counter by 4 n."""
+        d, n = self.diffusion, self.steps
+        corrupted = d.corrupt_step(x_start=self.batches[0], rng=(self.seed, self.counter))
+        outs = []
+        for i, x in enumerate(self.batches):
+            for p in params:
+                p.grad = None
+            last = i == n - 1
+            out = d.loss_step(self.model_fn, x_start=x, corrupted=corrupted, advance=4 * n if last else 0,
+                              prefetch=None if last else {"x_start": self.batches[i + 1], "offset": 4 * (i + 1)})
+            corrupted = out.pop("next", None)
+            outs.append(out)
+        return outs
 
     def replay(self):
         self.graph.replay()

@@ -203,6 +203,27 @@ int d3pm_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, long ld,
                      float* loss_mean, uint64_t* rng_counter, uint64_t rng_step,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* d3pm_hybrid_loss for this step, then the first two lines of training_losses
+ * (:549-556) for the NEXT batch -- what d3pm_q_sample_draw_t does, with the same
+ * Philox stream (seed, offset + *offset_dev) and the same result -- for a
+ * training loop whose batches are staged ahead of the step that consumes them
+ * (the reference's loop draws t and x_t at the top of every step, notebook
+ * cell-12; here step i's loss launch hands step i+1 its t and x_t).  One launch
+ * where the fused kernel takes the shape (column-structured tables, K = 32,
+ * 16-byte aligned rows with ld = K, B >= 192, npos <= 1024, a gradient asked
+ * for: the corruption runs while the loss's rows are on their way from memory),
+ * otherwise the two launches in sequence.  next_x_t / next_t_out must not be
+ * this step's x_t / t.  The Philox counter is only read here (offset_dev may be
+ * NULL): advance it with the rng_counter of a plain d3pm_hybrid_loss, e.g. the
+ * last step of a captured sequence. */
+int d3pm_hybrid_loss_then_q_sample(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0,
+                                   int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes,
+                                   int B, long npos, int loss_type, float hybrid_coeff, float grad_scale,
+                                   const float* grad_out, float* vb, float* ce, float* loss, float* dlogits,
+                                   void* workspace, size_t workspace_bytes, const void* next_x0,
+                                   int next_tok_bytes, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                   int32_t* next_t_out, int64_t* next_x_t, void* stream);
+
 /* d3pm_hybrid_loss for callers that cannot allocate device memory or carry a
  * workspace (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  No counterpart in the reference.  Same arguments, results

@@ -813,3 +813,52 @@ def test_training_step_several_steps_per_graph(pkg):
         np.testing.assert_allclose(float(g.outs[i]["loss"]), float(e["loss"]), rtol=1e-5)
     assert torch.equal(grad_graph, logits.grad)      # the last step's gradient
     assert not torch.equal(g.outs[0]["t"], g.outs[1]["t"])
+
+
+@pytest.mark.parametrize("kind,bits,B,L", [("uniform", 5, 256, 512), ("absorbing", 5, 200, 96), ("uniform", 5, 64, 48),
+                                            ("uniform", 4, 256, 128), ("gaussian", 4, 5, 40)])
+def test_pipelined_steps_equal_unpipelined(pkg, kind, bits, B, L):
+    """A graph whose loss launch of step i also draws the timesteps and noisy tokens of step i + 1
+    (d3pm_hybrid_loss_then_q_sample: one launch at K = 32 with a workgroup per batch element, two launches for the
+    other shapes) against the eager two-launch steps on the same Philox counter values: timesteps, tokens, losses and
+    the last gradient bit for bit, over two replays."""
+    K, T, n = 2 ** bits, 500, 4
+    betas = pkg.generate_betas(1e-4, 0.02, T, "linear") if kind == "gaussian" else pkg.generate_betas(0.0, 0.0, T, "jsd")
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type=kind, num_bits=bits, transition_bands=None,
+                              model_prediction="x_start", model_output="logits", loss_type="hybrid", hybrid_coeff=0.001,
+                              device=DEV)
+    gen = torch.Generator().manual_seed(B + L)
+    ring = [torch.randint(0, K, (B, L, 1, 1), generator=gen).to(DEV) for _ in range(n)]
+    logits = (torch.randn(B, L, 1, 1, K, generator=gen) * 2).to(DEV).requires_grad_(True)
+    fn = lambda x, tt: logits
+    g = pkg.graphs.GraphedTrainingStep(d, fn, ring, seed=5, params=[logits], steps=n, warmup=1, pipelined=True)
+    assert g.pipelined
+    start = int(g.counter.item())
+    assert start == 4 * n                            # the warm-up sequence advanced it once, by 4 n
+    counter = torch.full((1,), start, dtype=torch.int64, device=DEV)
+    static_grad = None
+    for rep in range(2):
+        g.replay()
+        assert int(g.counter.item()) == start + 4 * n * (rep + 1)
+        got = [{k: o[k].clone() for k in ("t", "x_t", "losses")} for o in g.outs]
+        if static_grad is None:
+            static_grad = logits.grad               # the buffer the captured last step writes on every replay
+        grad_graph = static_grad.clone()
+        for i in range(n):
+            logits.grad = None
+            e = d.training_step(fn, x_start=ring[i], rng=(5, counter))
+            for k in ("t", "x_t", "losses"):
+                assert torch.equal(got[i][k], e[k]), (rep, i, k)
+        assert torch.equal(grad_graph, logits.grad)
+        assert not torch.equal(got[0]["t"], got[1]["t"])
+    # eager use with torch's generator as the noise source: the next batch's corruption comes back under 'next'
+    torch.manual_seed(3)
+    c0 = d.corrupt_step(x_start=ring[0])
+    out = d.loss_step(fn, x_start=ring[0], corrupted=c0, prefetch={"x_start": ring[1]})
+    nxt = out["next"]
+    assert nxt["x_t"].shape == ring[1].shape and nxt["t"].shape == (B,)
+    assert int(nxt["x_t"].min()) >= 0 and int(nxt["x_t"].max()) < K and int(nxt["t"].max()) < T
+    ref = d._fused(logits.detach(), ring[0], c0["x_t"], c0["t"], "hybrid")
+    assert torch.equal(out["losses"], ref)
+    out2 = d.loss_step(fn, x_start=ring[1], corrupted=nxt)
+    assert torch.equal(out2["losses"], d._fused(logits.detach(), ring[1], nxt["x_t"], nxt["t"], "hybrid"))

@@ -78,6 +78,13 @@ def main():
             timed("hybrid_fwd", lambda: hybrid(False), (4 * K + 16) * B * L, "d3pm_hybrid_loss forward only, 4K+16 B/token")
             timed("q_sample", lambda: d.q_sample(x0, t), 16 * B * L,
                   "q_sample with device noise (facade call), 16 B/token")
+            t_nx = torch.empty(B, dtype=torch.int32, device=dev)
+            xt_nx = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
+            timed("hybrid_then_q", lambda: check(lib.d3pm_hybrid_loss_then_q_sample(
+                tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, LOSS["hybrid"], lam, 1.0 / B, None,
+                None, None, ptr(loss), ptr(dl), ptr(ws), wsb, ptr(x0), 8, 1, 0, None, ptr(t_nx), ptr(xt_nx), sp)),
+                  (8 * K + 32) * B * L, "d3pm_hybrid_loss_then_q_sample: loss fwd+bwd + the next batch's timestep draw "
+                  "and corruption in one launch, 8K+32 B/token")
             t_out = torch.empty(B, dtype=torch.int32, device=dev)
             xt_out = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
             timed("q_sample_draw_t", lambda: check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), 8, B, L, 1, 0, None, None,

@@ -49,6 +49,13 @@ if MODE == "nograd":
     def run():
         check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, LOSS["hybrid"],
                                    0.001, 1.0 / B, None, None, None, ptr(loss), None, None, None, 0, ptr(ws), wsb, sp))
+if MODE == "next":              # the launch that also corrupts the next batch
+    t_n = torch.empty(B, dtype=torch.int32, device=dev)
+    xt_n = torch.empty_like(xt)
+    def run():
+        check(lib.d3pm_hybrid_loss_then_q_sample(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                                 LOSS["hybrid"], 0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl),
+                                                 ptr(ws), wsb, ptr(x0), 8, 7, 0, None, ptr(t_n), ptr(xt_n), sp))
 for _ in range(20):
     run()
 torch.cuda.synchronize()
@@ -66,7 +73,7 @@ names = ["start", "t loaded", "digest rows arrived", "after barrier", "loop entr
          "first token pass done", "loop exit", "kernel end"]
 if os.environ.get("D3PM_LOSS_V", "3") == "3":       # the token-per-lane kernel
     names = ["start", "t loaded", "rows arrived, staged in LDS", "phase A done", "tables staged",
-             "phase B arithmetic done", "gradient rows in LDS, patched", "(unused)",
+             "phase B arithmetic done", "gradient rows in LDS, patched", "next batch drawn (next mode)",
              "global stores issued"]
 nw = int((tl[0, :, 0] != 0).sum())
 t0 = tl[:, :nw, 0].min()
