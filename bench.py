@@ -293,11 +293,20 @@ def worker(args):
                                                      pipelined=pipelined).replay
                  if spg > 1 else None)
 
+        # the steps left over when --steps is no multiple of n: one graph of that many steps (captured here, before
+        # the process group exists), so that they are not timed at one host-bound graph launch per step
+        rem = args.steps % spg if spg > 1 else 0
+        rest = (d3pm_amd.graphs.GraphedTrainingStep(dd, model_fn, x0, seed=seed + 1, params=[logits], steps=rem,
+                                                    pipelined=pipelined).replay if rem > 1 else None)
+
         def run_steps(k):
             if multi is not None:
                 for _ in range(k // spg):
                     multi()
                 k %= spg
+            if rest is not None and k == rem:
+                rest()
+                k = 0
             for _ in range(k):
                 one()
         return run_steps, one
