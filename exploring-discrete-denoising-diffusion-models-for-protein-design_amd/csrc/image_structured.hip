@@ -33,7 +33,7 @@ struct ImgArgs {
 
 // Digest component c (0 diag, 1 off, 2 log(diag+eps), 3 log(off+eps)) of matrix t.
 __device__ __forceinline__ const float* dg(const float* digest, int t, int c, int K) {
-  return digest + ((size_t)t * 4 + c) * K;
+  return digest + ((size_t)t * 8 + c) * K;        // c: 0 diag, 1 off, 2 log(diag+eps), 3 log(off+eps), 4-6 sampling rows
 }
 
 template <class L>
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample(ImgArgs a, const float* __re
 // drawn on the device the draw has two stages, from the two words of one
 // Philox2x32-10 call per token:
 //   x_t == x0 with probability (diag_x0 + eps) / (sum_j w_j), decided on a 32-bit
-//   integer threshold formed in float64 once per timestep (a step that moves one
-//   token in 10^5 keeps five digits of that probability);
+//   integer threshold formed in float64 when the digest is built (a step that moves
+//   one token in 10^5 keeps five digits of that probability);
 //   otherwise class j != x0 in proportion to off_j + eps: inverse CDF over the
 //   prefix sums of (off + eps), kept in LDS per workgroup, with x0's share taken
 //   out of the target; binary search, float32.
 // One thread per token, 16 bytes of traffic per token.  The per-launch key of the
 // token stream is a Philox4x32-10 call on (offset, seed), which the scalar unit
-// evaluates.  QsTables is the per-timestep part; a workgroup's first wave builds it.
+// evaluates.  QsTables is the per-timestep part, copied from rows 4-6 of the digest.
 template <int KMAX>
 struct QsTablesT {
   float cdf[KMAX + 1];   // cdf[j] = sum_{i<j} (off_i + eps)
@@ -128,82 +128,16 @@ struct QsTablesT {
 };
 typedef QsTablesT<256> QsTables;
 
-// Built by the 64 lanes of one wave (lane = 0..63) in two steps, so that a caller can put other requests between
-// the digest loads and their use; the caller puts a workgroup barrier between qs_finish and qs_draw.
-struct QsRows { float o[4], d[4]; };
-__device__ __forceinline__ QsRows qs_fetch(const float* __restrict__ digest, int t, int K, int lane) {
-  const float* dgd_ = dg(digest, t, 0, K);
-  const float* dgo_ = dg(digest, t, 1, K);
-  QsRows r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * lane + i;
-    r.o[i] = j < K ? dgo_[j] : 0.0f;
-    r.d[i] = j < K ? dgd_[j] : 0.0f;
-  }
-  return r;
-}
-// The same rows through the scalar unit (K a compile-time multiple of 4, at most 64): the 2 K values arrive in scalar
-// registers over the scalar cache's own path to L2 -- not behind whatever the compute unit's vector memory pipeline has
-// queued -- and are dealt to the lanes with one v_writelane each.  The digests are written once at set-up, long before
-// this launch: reading them through the constant address space is sound.
-template <int LANE>
-__device__ __forceinline__ void qs_writelane(int& dst, int val) {      // (the lane select has to be a literal: one
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(val), "n"(LANE)); // scalar register per instruction)
-}
-template <int KC, size_t... Js>
-__device__ __forceinline__ void qs_deal(int (&dst)[4], const int (&val)[KC], std::index_sequence<Js...>) {
-  (qs_writelane<(int)(Js / 4)>(dst[Js % 4], val[Js]), ...);
-}
-template <int KC>
-__device__ __forceinline__ QsRows qs_fetch_scalar(const float* __restrict__ digest, int t) {
-  typedef const int __attribute__((address_space(4))) cint;
-  cint* dd = (cint*)(uintptr_t)dg(digest, t, 0, KC);
-  cint* oo = (cint*)(uintptr_t)dg(digest, t, 1, KC);
-  int o[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
-  int ov[KC], dv[KC];
-#pragma unroll
-  for (int j = 0; j < KC; ++j) { ov[j] = oo[j]; dv[j] = dd[j]; }     // (all requests before the first use)
-  qs_deal(o, ov, std::make_index_sequence<KC>{});
-  qs_deal(d, dv, std::make_index_sequence<KC>{});
-  QsRows r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { r.o[i] = __builtin_bit_cast(float, o[i]); r.d[i] = __builtin_bit_cast(float, d[i]); }
-  return r;
-}
+// The per-timestep tables come ready from the digest (rows 4-6, built once at set-up: prefix sums in class order,
+// thresholds in float64): entry j is copied by thread / lane j; the caller orders the copy before qs_draw (a workgroup
+// barrier, or a wave-level fence for a wave-private copy).
 template <class Tables>
-__device__ __forceinline__ void qs_finish(Tables& q, const QsRows& r, int K, float eps, int lane) {
-#pragma clang fp contract(off)      // the same roundings in every kernel this is inlined into
-  float w[4], s = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    w[i] = 4 * lane + i < K ? r.o[i] + eps : 0.0f;
-    s += w[i];
-  }
-  // Up to 64 classes sit on the first 16 lanes: the scan stays inside a DPP row.  (The wider scan gives these lanes
-  // the same sums bit for bit -- its steps of 16 and 32 add nothing to them -- and its last lane the value of lane 15.)
-  float incl, tot;
-  if (K <= 64) {
-    incl = group_scan_inclusive<16>(s, lane & 15);
-    tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 15));
-  } else {
-    incl = group_scan_inclusive<64>(s, lane);
-    tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
-  }
-  const double total = (double)tot;
-  float run = incl - s;
-  if (lane == 0) q.cdf[0] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * lane + i;
-    run += w[i];
-    if (j < K) {
-      q.cdf[j + 1] = run;
-      q.w[j] = w[i];
-      const double d = (double)(r.d[i] + eps);
-      const double stay = d / (total - (double)w[i] + d);
-      q.stay[j] = stay >= 1.0 ? 0xffffffffu : (uint32_t)(stay * 4294967296.0);
-    }
+__device__ __forceinline__ void qs_copy(Tables& q, const float* __restrict__ digest, int t, int K, int j) {
+  if (j == 0) q.cdf[0] = 0.0f;
+  if (j < K) {
+    q.w[j] = dg(digest, t, 4, K)[j];
+    q.cdf[j + 1] = dg(digest, t, 5, K)[j];
+    q.stay[j] = __builtin_bit_cast(uint32_t, dg(digest, t, 6, K)[j]);
   }
 }
 
@@ -265,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
   } else {
     t = load_index(a.t, b, a.t_bytes, a.tb.T);
   }
-  if (threadIdx.x < 64) qs_finish(q, qs_fetch(a.tb.qbar_digest, t, K, threadIdx.x), K, a.tb.eps, threadIdx.x);
+  qs_copy(q, a.tb.qbar_digest, t, K, threadIdx.x);         // K <= 256 = BLOCK
   const QsKey key = qs_key(offset, seed);
   __syncthreads();
   for (long pos = pfirst; pos < p1; pos += blockDim.x) {
@@ -1101,8 +1035,8 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   __shared__ QsTablesT<KC> s_next[NEXT ? PW : 1];
   // The next batch's share of this launch, on the LAST threads of the workgroup (token blockDim.x - 1 - threadIdx.x;
   // the host launches this variant for npos <= blockDim.x).  A wave that holds such tokens does all of it on its own,
-  // BEFORE it asks for its rows: token load, timestep draw (scalar unit), digest rows of that timestep (scalar loads),
-  // per-timestep tables into the wave's own LDS copy, draw, store.  Rows are served in wave order and the vector
+  // BEFORE it asks for its rows: token load, timestep draw (scalar unit), the sampling rows of that timestep from the
+  // digest into the wave's own LDS copy, draw, store.  Rows are served in wave order and the vector
   // units work through a SIMD's waves in that order too, so these waves' rows would have waited for the arithmetic
   // of the earlier waves anyway; the waves without tokens run exactly the code of the plain kernel, and there is no
   // workgroup barrier.
@@ -1123,8 +1057,20 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       const int tok = *reinterpret_cast<const int*>((const char*)nx.x0 + (((size_t)b * a.npos + min(ntok, p1 - 1)) << nsh));
       const int tn = draw_timestep(b, a.tb.T, noff, nx.seed);
       if (ntok == 0) nx.t_out[b] = tn;
-      qs_finish(s_next[wave], qs_fetch_scalar<KC>(a.tb.qbar_digest, tn), KC, eps, lane);
+      // the sampling rows are requested into registers, the stream key is formed on the scalar unit meanwhile
+      float rw = 0, rc = 0, rs = 0;
+      if (lane < KC) {
+        rw = dg(a.tb.qbar_digest, tn, 4, KC)[lane];
+        rc = dg(a.tb.qbar_digest, tn, 5, KC)[lane];
+        rs = dg(a.tb.qbar_digest, tn, 6, KC)[lane];
+      }
       const QsKey key = qs_key(noff, nx.seed);
+      if (lane == 0) s_next[wave].cdf[0] = 0.0f;
+      if (lane < KC) {
+        s_next[wave].w[lane] = rw;
+        s_next[wave].cdf[lane + 1] = rc;
+        s_next[wave].stay[lane] = __builtin_bit_cast(uint32_t, rs);
+      }
       wave_lds_fence();
       const uint64_t n = (uint64_t)b * (uint64_t)a.npos + ntok;
       if (ntok < p1) nx.x_t[n] = qs_draw(s_next[wave], KC, clamp_index(tok, KC), n, key);

@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
   const int t = blockIdx.x;
   const double* m = table + (long)t * st;
   constexpr bool F32 = sizeof(OutT) == 4;
-  constexpr int NV = 4;                 // diag, off, log(diag [+eps]), log(off [+eps])
+  // diag, off, log(diag [+eps]), log(off [+eps]); the float32 digest carries four more rows for sampling from a row of
+  // the table with weights p + eps (what q_sample does): w = off + eps, its inclusive prefix sums, the probability of
+  // staying in class j when starting there as a 32-bit integer threshold, and a spare row
+  constexpr int NV = F32 ? 8 : 4;
   OutT* dg = digest + (size_t)t * NV * K;
   int bad = 0;
   for (int e = threadIdx.x; e < K * K; e += blockDim.x) {
@@ -189,6 +192,27 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
     }
   }
   if (bad) atomicAdd(violations, bad);
+  if constexpr (F32) {
+    __syncthreads();                    // the rows above are this workgroup's own writes
+    if (threadIdx.x == 0) {
+      const float eps = (float)tol_or_eps;
+      float run = 0;
+      for (int j = 0; j < K; ++j) {     // float32 prefix sums in class order: the inverse CDF the samplers search
+        const float w = dg[1 * K + j] + eps;
+        run += w;
+        dg[4 * K + j] = w;
+        dg[5 * K + j] = run;
+      }
+      const double total = (double)run;
+      for (int j = 0; j < K; ++j) {
+        const double d = (double)(dg[0 * K + j] + eps), w = (double)dg[4 * K + j];
+        const double stay = d / (total - w + d);             // in float64: a probability of 1 - 1e-5 keeps its digits
+        const unsigned bits = stay >= 1.0 ? 0xffffffffu : (unsigned)(stay * 4294967296.0);
+        dg[6 * K + j] = __builtin_bit_cast(float, bits);
+        dg[7 * K + j] = 0.0f;
+      }
+    }
+  }
 }
 
 __global__ void k_cast_f32(const double* __restrict__ table, long st, long sr, long sc, int K, float* __restrict__ out) {

@@ -46,8 +46,8 @@ class ImageTables:
         T, K = self.T, self.K
         with torch.cuda.device(self.device):
             s = stream_ptr()
-            self.qbar_digest = torch.empty((T, 4, K), dtype=torch.float32, device=self.device)
-            self.qone_digest = torch.empty((T, 4, K), dtype=torch.float32, device=self.device)
+            self.qbar_digest = torch.empty((T, 8, K), dtype=torch.float32, device=self.device)
+            self.qone_digest = torch.empty((T, 8, K), dtype=torch.float32, device=self.device)
             viol = torch.zeros(2, dtype=torch.int32, device=self.device)
             check(lib.d3pm_digest_f32(ptr(q_mats), *_strides3(q_mats), T, K, self.eps, ptr(self.qbar_digest),
                                       viol.data_ptr(), s))

@@ -92,7 +92,10 @@ int d3pm_cumprod_f64(int K, int T, const double* mats, long st, long sr, long sc
  * (st, sr, sc): if, after the float32 cast the reference applies in _at
  * (d3pm/diffusion_discrete.py:218), every column j of every matrix t has one
  * off-diagonal value, the table is  entry(i,j) = i==j ? diag[t][j] : off[t][j].
- * digest is float32 [T][4][K]: diag, off, log(diag+eps), log(off+eps).
+ * digest is float32 [T][8][K]: diag, off, log(diag+eps), log(off+eps), and four
+ * rows for sampling a row of the table with weights p + eps (the Gumbel-max of
+ * q_sample :266-285 draws from those): w = off+eps, its inclusive prefix sums,
+ * P(stay in class j) as a 32-bit integer threshold (bit pattern), one spare row.
  * *violations (device int, zeroed by the caller) counts entries that break the
  * structure; the dense path must be used when it is non-zero. */
 int d3pm_digest_f32(const double* table, long st, long sr, long sc, int T, int K, float eps,
@@ -115,8 +118,8 @@ typedef struct d3pm_tables_f32 {
   int K, T;
   int structured;
   float eps;                 /* 1e-6, DiscreteDiffusion.eps (:49) */
-  const float* qbar_digest;  /* [T][4][K] of q_mats                       */
-  const float* qone_digest;  /* [T][4][K] of the one-step Q_t             */
+  const float* qbar_digest;  /* [T][8][K] of q_mats                       */
+  const float* qone_digest;  /* [T][8][K] of the one-step Q_t             */
   const float* qbar;         /* [T][K][K] q_mats, float32 (dense only)    */
   const float* qoneT;        /* [T][K][K] transpose_q_onestep_mats (dense)*/
   const float* qbarT;        /* [T][K][K] q_mats transposed (dense, for the backward contraction) */

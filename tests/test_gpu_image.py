@@ -521,7 +521,7 @@ def test_raw_ctypes_binding_as_documented(pkg):
                               loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
     q_mats = d.q_mats.to(DEV)
     qone = d.transpose_q_onestep_mats.to(DEV).permute(0, 2, 1)
-    dg_bar, dg_one = torch.empty(T, 4, K, device=DEV), torch.empty(T, 4, K, device=DEV)
+    dg_bar, dg_one = torch.empty(T, 8, K, device=DEV), torch.empty(T, 8, K, device=DEV)
     viol = torch.zeros(2, dtype=torch.int32, device=DEV)
     s = torch.cuda.current_stream().cuda_stream
     for tab, dg, off in ((q_mats, dg_bar, 0), (qone, dg_one, 4)):
