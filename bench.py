@@ -443,9 +443,36 @@ def worker(args):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
+    def event_ms_replayed(fn_on, n, per_graph=50):
+        """The same figure with the host out of the way: `per_graph` launches of fn_on(stream pointer) captured back to
+        back into a HIP graph, replays timed between two HIP events on the replay stream (a Python call per launch
+        takes about as long as these kernels run, so eager back-to-back timing sits at the edge of being host-bound)."""
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn_on(stream_ptr())
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            spc = stream_ptr()
+            for _ in range(per_graph):
+                fn_on(spc)
+        reps = max(2, -(-n // per_graph))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * per_graph)
+
     # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
     # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
-    def fused_kernel_ms(dd, nsets=1, with_next=False):
+    def fused_kernel_ms(dd, nsets=1, with_next=False, replayed=False):
         """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
         launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
         tb = dd.tables()
@@ -460,12 +487,14 @@ def worker(args):
         ws = torch.empty(max(wsb // 4, 1), device=dev)
         state = {"i": 0}
 
-        def fused_only():
+        def fused_only(spx=None):
             x0_i, xt_i, lg_i, dl_i = sets[state["i"] % nsets]
             state["i"] += 1
             check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
                                        LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
-                                       None, 0, ptr(ws), wsb, sp))
+                                       None, 0, ptr(ws), wsb, sp if spx is None else spx))
+        if replayed:
+            return event_ms_replayed(fused_only, max(args.steps, 200), per_graph=10 * nsets if nsets > 1 else 50)
         if not with_next:
             return event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10)
         t_n = torch.empty(B, dtype=torch.int32, device=dev)
@@ -483,6 +512,7 @@ def worker(args):
     kern_ms = fused_kernel_ms(d)
     kern_rot_ms = None if args.no_secondary else fused_kernel_ms(d, nsets=10)
     kern_next_ms = fused_kernel_ms(d, with_next=True) if pipelined else None
+    kern_replayed_ms = fused_kernel_ms(d, replayed=True) if not args.no_graph and not use_pg else None
 
     progress("absorbing")
     absorbing = None
@@ -641,6 +671,9 @@ def worker(args):
                 "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
                         "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "
                         "i.e. served from HBM"}
+        if kern_replayed_ms:
+            roof["kernel_ms_graph_replayed"] = kern_replayed_ms
+            roof["frac_graph_replayed"] = BYTES_PER_TOKEN * B * L / (kern_replayed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if kern_next_ms:
             # the launch the pipelined step actually makes: the same kernel carrying the next batch's timestep draw
             # and corruption (k_hybrid_loss_pair32<true, true>): 16 more bytes per token
