@@ -661,12 +661,12 @@ def worker(args):
     progress("sections done")
     if rank == 0:
         achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
-        traffic = measured_traffic("k_hybrid_loss_pair32<true>")
+        traffic = measured_traffic("k_hybrid_loss_pair32<true, false>")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": (traffic["source"] + " (a committed rocprofv3 --pmc pass of this command, not "
                                    "measured by this run)") if traffic else None,
-                "kernel": "k_hybrid_loss_pair32<true> via d3pm_hybrid_loss, back-to-back launches between two HIP events",
+                "kernel": "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss, back-to-back launches between two HIP events",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
                 "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
                         "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "
