@@ -436,6 +436,11 @@ def worker(args):
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
+        until = time.perf_counter() + 0.1            # sustained clocks before anything is timed
+        while time.perf_counter() < until:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
         e0.record()
         for _ in range(n):
             fn()
