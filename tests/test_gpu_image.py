@@ -862,3 +862,36 @@ def test_pipelined_steps_equal_unpipelined(pkg, kind, bits, B, L):
     assert torch.equal(out["losses"], ref)
     out2 = d.loss_step(fn, x_start=ring[1], corrupted=nxt)
     assert torch.equal(out2["losses"], d._fused(logits.detach(), ring[1], nxt["x_t"], nxt["t"], "hybrid"))
+
+
+@pytest.mark.parametrize("kind,bits", [("uniform", 5), ("absorbing", 4), ("uniform", 8)])
+def test_digest_sampling_rows(pkg, kind, bits):
+    """Rows 4-6 of the float32 digest, which the device-noise q_sample kernels copy: w = off + eps, its prefix sums
+    in class order (float32, sequential), and P(x_t == x0 = j) = (diag_j + eps) / (sum w - w_j + diag_j + eps) as a
+    32-bit integer threshold formed in float64."""
+    K, T = 2 ** bits, 60
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type=kind, num_bits=bits,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    tb = d.tables()
+    assert tb.structured and tb.qbar_digest.shape == (T, 8, K)
+    dg = tb.qbar_digest.cpu().numpy()
+    eps = np.float32(1e-6)
+    qm = d.q_mats.cpu().numpy()
+    for t in (0, 1, T // 2, T - 1):
+        diag = np.diagonal(qm[t]).astype(np.float32)
+        off = np.array([qm[t][1 if j == 0 else 0, j] for j in range(K)], dtype=np.float32)
+        np.testing.assert_array_equal(dg[t, 0], diag)
+        np.testing.assert_array_equal(dg[t, 1], off)
+        w = off + eps
+        np.testing.assert_array_equal(dg[t, 4], w)
+        run, cdf = np.float32(0), []
+        for j in range(K):
+            run = np.float32(run + w[j])
+            cdf.append(run)
+        np.testing.assert_array_equal(dg[t, 5], np.array(cdf, dtype=np.float32))
+        dd = (diag + eps).astype(np.float64)
+        stay = dd / (np.float64(cdf[-1]) - w.astype(np.float64) + dd)
+        want = np.where(stay >= 1.0, 0xFFFFFFFF, np.minimum(stay * 4294967296.0, 4294967295.0)).astype(np.uint64)
+        got = dg[t, 6].view(np.uint32).astype(np.uint64)
+        assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1, (t, got[:4], want[:4])
