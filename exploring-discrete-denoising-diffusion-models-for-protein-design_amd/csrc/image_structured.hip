@@ -1109,6 +1109,13 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         const unsigned q = h * 64 + lane;
         *reinterpret_cast<v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16) = stage[h];
       }
+      if (first && need_post && lane < KC) {
+        // this wave's table copy goes to LDS together with the rows (the digest values were requested right behind
+        // the rows and arrive with them): the fence below covers both, and nothing waits on LDS after phase A
+        s_tab[wave][0][lane] = v_ad + eps;
+        s_tab[wave][1][lane] = v_ao + eps;
+        s_tab[wave][2][lane] = vo + eps;
+      }
       if (first) D3PM_TL(2);
       wave_lds_fence();
 #pragma unroll
@@ -1133,25 +1140,20 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     if (first) {
       first = false;
       if (need_post) {
-        if (lane < KC) {
-          s_tab[wave][0][lane] = v_ad + eps;
-          s_tab[wave][1][lane] = v_ao + eps;
-          s_tab[wave][2][lane] = vo + eps;
-        }
         bdo = lane_bcast(vd - vo, 0);
         sum_boe = (1.0f - bdo) + (float)KC * eps;           // rows of Qbar_{t-1} sum to one
-        wave_lds_fence();                     // this wave's table copy
+        // bit q of same_w: classes 4q .. 4q+3 of BOTH halves have one off-diagonal weight each.  Lane j < 32 holds
+        // class j's weight, so a group of four classes is a quad of lanes: two DPP compares and a ballot, no LDS
+        const float bo = vo + eps;
+        const bool quad_eq = (bo == partner<1>(bo)) && (bo == partner<2>(bo));
+        unsigned mk = (unsigned)__builtin_amdgcn_ballot_w64(quad_eq);   // lanes 0 .. 31
+        mk &= mk >> 1;
+        mk &= mk >> 2;                                      // bit 4g: all four lanes of quad g agree
         unsigned sw = 0;
 #pragma unroll
-        for (int q = 0; q < HC / 4; ++q) {
-          const v4f_nt w = my_boe[q];
-          const bool eq = w.x == w.y && w.x == w.z && w.x == w.w;
-          const bool all = __builtin_amdgcn_ballot_w64(eq) == ~0ull;
-          sw |= (all ? 1u : 0u) << q;
-        }
+        for (int q = 0; q < HC / 4; ++q) sw |= ((mk >> (4 * q)) & (mk >> (4 * q + 16)) & 1u) << q;
         same_w = __builtin_amdgcn_readfirstlane(sw);
       }
-      wave_lds_fence();
       D3PM_TL(4);
     }
     if (!work) break;
