@@ -37,8 +37,16 @@ __device__ __forceinline__ float log1p_acc(float q) {
   return fmaf(fast_log2(u), LN2, (q - (u - 1.0f)) * fast_rcp(u));
 }
 
+// The same for 0 <= q <= 1 (u in [1, 2]): 1 / u in the first-order term replaced by 2 - u, which is within 25 % of it;
+// the term itself is at most half an ulp of u, so the result moves by less than a fifth of an ulp -- and a
+// transcendental (four issue slots) becomes one subtraction.
+__device__ __forceinline__ float log1p_unit(float q) {
+  const float u = 1.0f + q;
+  return fmaf(fast_log2(u), LN2, (q - (u - 1.0f)) * (2.0f - u));
+}
+
 // log(sigmoid(x)) = min(x, 0) - log1p(exp(-|x|))
-__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.0f) - log1p_acc(exp_acc(-fabsf(x))); }
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.0f) - log1p_unit(exp_acc(-fabsf(x))); }
 // its derivative sigmoid(-x), in the two-sided form that keeps small values exact
 __device__ __forceinline__ float log_sigmoid_grad(float x) {
   const float z = exp_acc(-fabsf(x));
@@ -60,7 +68,8 @@ __global__ __launch_bounds__(LG_BLOCK) void k_logistic_logits(LogisticArgs a, fl
       const float d = a.centers[k] - loc;
       const float lo = log_sigmoid(inv_scale * (d - a.half_width));
       const float hi = log_sigmoid(inv_scale * (d + a.half_width));
-      out[n * a.K + k] = hi + log1p_acc(-exp_acc(lo - hi) + a.eps);
+      // (a streamed output: nothing in this launch reads it back)
+      __builtin_nontemporal_store(hi + log1p_acc(-exp_acc(lo - hi) + a.eps), out + (n * a.K + k));
     }
   }
 }
