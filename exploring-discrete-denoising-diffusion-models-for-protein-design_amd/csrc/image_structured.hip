@@ -170,12 +170,33 @@ __device__ __forceinline__ int qs_draw(const Tables& q, int K, int x0, uint64_t 
   return l;
 }
 
-// With `t_draw` the timestep of each batch element is drawn here as well,
-// uniform on [0, T) from the same Philox key (counter 2^63 + b, disjoint from the
-// token counters), and written to t_draw[b] for the denoiser and the loss.
-__device__ __forceinline__ int draw_timestep(int b, int T, uint64_t offset, uint64_t seed) {
-  const U4 r = philox4x32_10((1ull << 63) + (uint64_t)b, offset, seed);
+// With `t_draw` the timestep of each batch element is drawn here as well, uniform on [0, T): one Philox2x32-10 call
+// per batch element under the launch's key with its last word inverted (a key of its own: disjoint from the token
+// stream), written to t_draw[b] for the denoiser and the loss.
+__device__ __forceinline__ int draw_timestep(int b, int T, QsKey key) {
+  const U2 r = philox2x32_10((uint32_t)b ^ key.x, key.y ^ 0x9E3779B9u, ~key.z);
   return (int)(((uint64_t)r.x * (uint64_t)T) >> 32);
+}
+__device__ __forceinline__ int draw_timestep(int b, int T, uint64_t offset, uint64_t seed) {
+  return draw_timestep(b, T, qs_key(offset, seed));
+}
+
+// qs_draw's search as a count, for a compile-time K: cdf is non-decreasing, so the largest j with cdf[j] <= rr is the
+// number of entries cdf[1 .. K-1] that are <= rr -- the same index the bisection finds, from K / 4 wide LDS reads
+// issued together instead of log2(K) dependent ones.
+template <int KC, class Tables>
+__device__ __forceinline__ int qs_draw_counted(const Tables& q, int x0, uint64_t n, QsKey key) {
+#pragma clang fp contract(off)      // the same roundings as qs_draw
+  const U2 r = philox2x32_10((uint32_t)n ^ key.x, (uint32_t)(n >> 32) ^ key.y, key.z);
+  if (r.y < q.stay[x0]) return x0;
+  const float lo = q.cdf[x0], wx = q.w[x0];
+  const float target = u01_open(r.x) * (q.cdf[KC] - wx);
+  const float rr = target < lo ? target : target + wx;
+  int l = 0;
+#pragma unroll
+  for (int j = 1; j < KC; ++j) l += (q.cdf[j] <= rr) ? 1 : 0;
+  if (l == x0) l = (target < lo) ? (x0 > 0 ? x0 - 1 : (KC > 1 ? 1 : 0)) : (x0 + 1 < KC ? x0 + 1 : (KC > 1 ? KC - 2 : 0));
+  return l;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t seed, uint64_t offset,
@@ -192,15 +213,15 @@ __global__ __launch_bounds__(BLOCK) void k_q_sample_icdf(ImgArgs a, uint64_t see
   // the first token's load is in flight while the timestep -> digest -> prefix-sum chain runs
   int x0_next = 0;
   if (pfirst < p1) x0_next = load_index(a.x0, (long)b * a.npos + pfirst, a.x0_bytes, a.tb.K);
+  const QsKey key = qs_key(offset, seed);
   int t;
   if (t_draw) {
-    t = draw_timestep(b, a.tb.T, offset, seed);
+    t = draw_timestep(b, a.tb.T, key);
     if (chunk == 0 && threadIdx.x == 0) t_draw[b] = t;
   } else {
     t = load_index(a.t, b, a.t_bytes, a.tb.T);
   }
   qs_copy(q, a.tb.qbar_digest, t, K, threadIdx.x);         // K <= 256 = BLOCK
-  const QsKey key = qs_key(offset, seed);
   __syncthreads();
   for (long pos = pfirst; pos < p1; pos += blockDim.x) {
     const long n = (long)b * a.npos + pos;
@@ -1045,6 +1066,9 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     if (blockDim.x - 64u * (unsigned)(wave + 1) < p1) {       // (uniform over the wave)
       __builtin_amdgcn_s_setprio(3);            // ahead of the other waves' arithmetic: this wave's rows wait on it
       const unsigned nsh = nx.x0_bytes == 8 ? 3 : 2;          // the low dword of a token, either width
+      // requested first, used after the tables are in LDS (no branch around the load: the compiler would put the
+      // clamp, and with it the wait, inside the branch)
+      const int tok = *reinterpret_cast<const int*>((const char*)nx.x0 + (((size_t)b * a.npos + min(ntok, p1 - 1)) << nsh));
       uint64_t noff = nx.offset;
       if (nx.offset_dev) {
         // a scalar load (the counter is written by earlier launches only)
@@ -1052,19 +1076,16 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(nx.offset_dev));
         noff += c;
       }
-      // requested here, used after the tables are built (no branch around the load: the compiler would put the
-      // clamp, and with it the wait, inside the branch)
-      const int tok = *reinterpret_cast<const int*>((const char*)nx.x0 + (((size_t)b * a.npos + min(ntok, p1 - 1)) << nsh));
-      const int tn = draw_timestep(b, a.tb.T, noff, nx.seed);
+      const QsKey key = qs_key(noff, nx.seed);
+      const int tn = draw_timestep(b, a.tb.T, key);
       if (ntok == 0) nx.t_out[b] = tn;
-      // the sampling rows are requested into registers, the stream key is formed on the scalar unit meanwhile
+      // the sampling rows of that timestep
       float rw = 0, rc = 0, rs = 0;
       if (lane < KC) {
         rw = dg(a.tb.qbar_digest, tn, 4, KC)[lane];
         rc = dg(a.tb.qbar_digest, tn, 5, KC)[lane];
         rs = dg(a.tb.qbar_digest, tn, 6, KC)[lane];
       }
-      const QsKey key = qs_key(noff, nx.seed);
       if (lane == 0) s_next[wave].cdf[0] = 0.0f;
       if (lane < KC) {
         s_next[wave].w[lane] = rw;
@@ -1073,7 +1094,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       }
       wave_lds_fence();
       const uint64_t n = (uint64_t)b * (uint64_t)a.npos + ntok;
-      if (ntok < p1) nx.x_t[n] = qs_draw(s_next[wave], KC, clamp_index(tok, KC), n, key);
+      if (ntok < p1) nx.x_t[n] = qs_draw_counted<KC>(s_next[wave], clamp_index(tok, KC), n, key);
       D3PM_TL(7);
       __builtin_amdgcn_s_setprio(0);
     }
