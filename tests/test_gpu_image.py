@@ -895,3 +895,33 @@ def test_digest_sampling_rows(pkg, kind, bits):
         want = np.where(stay >= 1.0, 0xFFFFFFFF, np.minimum(stay * 4294967296.0, 4294967295.0)).astype(np.uint64)
         got = dg[t, 6].view(np.uint32).astype(np.uint64)
         assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1, (t, got[:4], want[:4])
+
+
+def test_then_q_sample_refuses_aliased_outputs(pkg):
+    """d3pm_hybrid_loss_then_q_sample reads this step's x_t / t while it writes the next step's: the same buffers for
+    both are refused before anything is launched."""
+    from d3pm_amd._lib import lib, ptr, stream_ptr, LOSS
+    K, T, B, L = 32, 50, 4, 40
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    tb = d.tables()
+    x0 = torch.randint(0, K, (B, L), device=DEV)
+    t = torch.randint(0, T, (B,), dtype=torch.int32, device=DEV)
+    xt = d.q_sample(x0.view(B, L, 1, 1), t).view(B, L)
+    lg = torch.randn(B, L, K, device=DEV)
+    dl, loss = torch.empty_like(lg), torch.empty(B, device=DEV)
+    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+    ws = torch.empty(max(wsb // 4, 1), device=DEV)
+    t2, xt2 = torch.empty_like(t), torch.empty_like(xt)
+
+    def call(next_t, next_xt):
+        return lib.d3pm_hybrid_loss_then_q_sample(tb.desc(), ptr(lg), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                                  LOSS["hybrid"], 0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl),
+                                                  ptr(ws), wsb, ptr(x0), 8, 5, 0, None, ptr(next_t), ptr(next_xt),
+                                                  stream_ptr())
+    assert call(t2, xt) != 0 and b"must not be" in lib.d3pm_last_error()
+    assert call(t, xt2) != 0
+    assert call(t2, xt2) == 0
+    torch.cuda.synchronize()
+    assert int(xt2.min()) >= 0 and int(xt2.max()) < K and int(t2.min()) >= 0 and int(t2.max()) < T
