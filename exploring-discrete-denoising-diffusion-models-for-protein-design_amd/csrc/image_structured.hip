@@ -10,6 +10,7 @@
 // timestep's digest rows in registers, and reduces over K with DPP butterflies
 // inside lane groups.
 #include "layout.h"
+#include "rowimage.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -1409,6 +1410,113 @@ __global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __re
   }
 }
 
+// ------------------------------------------------------------------ p_sample, device noise, one token per lane
+// The reverse step of the sampling loop (no probabilities out, noise drawn on the device) for K = 32 with the tokens
+// of the whole batch taken as one row, as k_lvb_reverse_flat does for the protein-style step: wave w owns tokens
+// 64 w .. 64 w + 63, rows through the wave-private LDS image with division-free addressing, and the draw is an in-lane
+// inverse CDF over the unnormalised posterior (a_j + eps)(f2_j + eps).  The factor a_off + eps is divided out: generic
+// weights g_j = (off_j + eps) + (diag - off) pi_j, whose running sum is MO_j + c P_j with MO the digest's own prefix
+// row (wave-uniform) and P_j the running sum of the softmax pass, plus an extra mass X on class x_t; one uniform
+// decides both.  t == 0: argmax of the logits (first maximum), as with explicit noise.  A wave that straddles two
+// batch elements with different timesteps runs the per-timestep part once for each.
+template <int KC>
+__global__ __launch_bounds__(256) void k_p_sample_flat(ImgArgs a, const float* __restrict__ logits, uint64_t seed,
+                                                       uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                       int64_t* __restrict__ sample, unsigned ntok, float inv_npos) {
+  using Img = RowImage<KC>;
+  extern __shared__ __align__(16) char flat_rows[];         // [waves][64][STRIDE]
+  __shared__ float s_tab[4][3][KC];                         // per wave: a_diag + eps, a_off + eps of Q_t by x_t; off + eps
+  const float eps = a.tb.eps;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
+  if (base >= ntok) return;                                 // (uniform over the wave; the kernel has no barrier)
+  const unsigned np = (unsigned)a.npos;
+  unsigned b0 = __builtin_amdgcn_readfirstlane((unsigned)((float)base * inv_npos));   // off by one at most (B <= 2^20)
+  int r0 = (int)(base - b0 * np);
+  if (r0 < 0) { b0 -= 1; r0 += (int)np; }
+  else if (r0 >= (int)np) { b0 += 1; r0 -= (int)np; }
+  const bool second = (unsigned)r0 + lane >= np;            // this lane's token belongs to batch element b0 + 1
+  const unsigned nrows = min(64u, ntok - base);
+  const bool spans = (unsigned)r0 + nrows > np;             // (uniform)
+  char* const img = flat_rows + (size_t)wave * Img::BYTES;
+  Img rows;
+  rows.request_flat((const char*)logits + (size_t)base * Img::RB, nrows * Img::RB - Img::PB, lane, nrows == 64);
+  const unsigned xsh = a.xt_bytes == 8 ? 3 : 2;             // the low dword of a token, either width
+  int xt = *reinterpret_cast<const int*>((const char*)a.xt + ((size_t)(base + min((unsigned)lane, nrows - 1)) << xsh));
+  const int t0 = load_index(a.t, b0, a.t_bytes, a.tb.T);
+  const int t1 = spans ? load_index(a.t, b0 + 1, a.t_bytes, a.tb.T) : t0;
+  const bool two = t1 != t0;                                // (uniform)
+  float vd = 0, vw = 0, vc = 0, ad = 0, ao = 0;
+  auto fetch = [&](int t) {
+    if (t > 0 && lane < KC) {
+      vd = dg(a.tb.qbar_digest, t - 1, 0, KC)[lane] - dg(a.tb.qbar_digest, t - 1, 1, KC)[lane];
+      vw = dg(a.tb.qbar_digest, t - 1, 4, KC)[lane];        // off + eps
+      vc = dg(a.tb.qbar_digest, t - 1, 5, KC)[lane];        // its inclusive prefix sums
+      ad = dg(a.tb.qone_digest, t, 0, KC)[lane] + eps;
+      ao = dg(a.tb.qone_digest, t, 1, KC)[lane] + eps;
+    }
+  };
+  fetch(t0);
+  if (offset_dev) offset += *offset_dev;
+  const QsKey key = qs_key(offset, seed);
+  const U2 rnd = philox2x32_10((base + lane) ^ key.x, key.y, key.z);
+  const float u = u01_open(rnd.x);
+  xt = clamp_index(xt, KC);
+  rows.deposit_flat(img, lane, Img::split(lane));
+  wave_lds_order();
+  float z[KC];
+  Img::read_row(img, lane, z);
+  const float z_xt = *reinterpret_cast<const float*>(img + lane * Img::STRIDE + 4 * xt);
+  float m = z[0];
+  int amax = 0;
+#pragma unroll
+  for (int j = 1; j < KC; ++j) {
+    amax = z[j] > m ? j : amax;                             // first maximum, as torch.argmax
+    m = fmaxf(m, z[j]);
+  }
+  const float mneg = -m * LOG2E;
+  float P[KC];                                              // running sums of e_j
+  float acc = 0;
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    acc += fast_exp2(fmaf(z[j], LOG2E, mneg));
+    P[j] = acc;
+  }
+  const float e_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg));
+  const float inv_s = fast_rcp(acc);
+  auto draw = [&](int t) {
+    if (t == 0) return amax;                                // (uniform)
+    if (lane < KC) {
+      s_tab[wave][0][lane] = ad;
+      s_tab[wave][1][lane] = ao;
+      s_tab[wave][2][lane] = vw;
+    }
+    const float c = lane_broadcast(vd, 0) * inv_s;          // diag - off is one value for all classes
+    float MO[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) MO[j] = lane_broadcast(vc, j);
+    wave_lds_order();
+    const float G = fmaf(P[KC - 1], c, MO[KC - 1]);
+    const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt];
+    const float g_xt = fmaf(e_xt, c, s_tab[wave][2][xt]);
+    const float X = (a_d - a_o) * fast_rcp(a_o) * g_xt;
+    const float target = u * (G + X) - X;                   // < 0: the extra mass of x_t was hit
+    int cnt = 0;                                            // classes whose cumulative weight is <= target
+#pragma unroll
+    for (int j = 0; j < KC - 1; ++j) cnt += (fmaf(P[j], c, MO[j]) <= target) ? 1 : 0;
+    return target < 0.0f ? xt : cnt;
+  };
+  int pick = draw(t0);
+  if (two) {                                                // (uniform) the wave's second batch element, own timestep
+    wave_lds_order();
+    fetch(t1);
+    const int p1 = draw(t1);
+    pick = second ? p1 : pick;
+  }
+  if (lane < (int)nrows) sample[base + lane] = pick;
+}
+
 // ------------------------------------------------------------------ prior_bpd
 template <class L>
 __global__ __launch_bounds__(BLOCK) void k_prior(ImgArgs a, int absorbing, float* __restrict__ part) {
@@ -1938,6 +2046,18 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
                           sample, probs, s);
   const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
                    (!probs || aligned16(probs));
+  static const bool allow_flat = !(getenv("D3PM_PSAMPLE_FLAT") && !atoi(getenv("D3PM_PSAMPLE_FLAT")));
+  if (allow_flat && noise_kind == D3PM_NOISE_PHILOX && !probs && vec && tb->K == 32 && npos >= 64 && B <= (1 << 20) &&
+      (long)B * npos * ld < 0x3fffffffL) {
+    // the sampling loop's call: tokens of the whole batch as one row, 64 per wave
+    ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, 1);
+    const unsigned ntok = (unsigned)((long)B * npos), waves = (ntok + 63) / 64, wpb = 4;
+    hipLaunchKernelGGL((k_p_sample_flat<32>), dim3((waves + wpb - 1) / wpb), dim3(64 * wpb),
+                       (size_t)wpb * RowImage<32>::BYTES, s, a, logits, seed, offset, offset_dev, sample, ntok,
+                       1.0f / (float)npos);
+    D3PM_LAUNCH_CHECK("k_p_sample_flat");
+    return D3PM_OK;
+  }
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, L::G);

@@ -925,3 +925,37 @@ def test_then_q_sample_refuses_aliased_outputs(pkg):
     assert call(t2, xt2) == 0
     torch.cuda.synchronize()
     assert int(xt2.min()) >= 0 and int(xt2.max()) < K and int(t2.min()) >= 0 and int(t2.max()) < T
+
+
+def test_p_sample_flat_mixed_timesteps(pkg):
+    """The sampling loop's p_sample at K = 32 (device noise, no probabilities out) takes the flat token-per-lane
+    kernel: 64 consecutive tokens of the batch per wave, so with 100 positions per batch element most waves hold
+    tokens of two batch elements with different timesteps (one of them t = 0: argmax of the logits).  Class
+    frequencies per timestep against softmax of the parity-tested posterior logits; same stream, same draw."""
+    K, T, L = 32, 50, 100
+    ts = [0, 1, 7, 33, 49]
+    B = len(ts) * 400
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    gen = torch.Generator().manual_seed(8)
+    row = (2.0 * torch.randn(K, generator=gen)).to(DEV)
+    logits = row.expand(B, L, 1, 1, K).contiguous()
+    x_t = torch.full((B, L, 1, 1), 11, device=DEV)
+    t = torch.tensor(ts, dtype=torch.int32).repeat(B // len(ts)).to(DEV)
+    c = torch.zeros(1, dtype=torch.int64, device=DEV)
+    s, none = d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False, rng=(4, c, 0))
+    again, _ = d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False, rng=(4, c, 0))
+    assert none is None and torch.equal(s, again)
+    other, _ = d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False, rng=(4, c, 4))
+    assert not torch.equal(s, other)
+    post = d.q_posterior_logits(logits[:len(ts), :1], x_t[:len(ts), :1], t[:len(ts)], x_start_logits=True)
+    P = torch.softmax(post.double(), -1).reshape(len(ts), K).cpu().numpy()
+    for i, tv in enumerate(ts):
+        part = s[i::len(ts)]
+        n = part.numel()
+        freq = torch.bincount(part.flatten().cpu(), minlength=K).numpy() / n
+        if tv == 0:
+            assert freq[int(row.argmax())] == 1.0
+        else:
+            assert (np.abs(freq - P[i]) < 5 * np.sqrt(P[i] * (1 - P[i]) / n) + 2e-5).all(), (tv, np.abs(freq - P[i]).max())

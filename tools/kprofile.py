@@ -78,6 +78,10 @@ def main():
             timed("hybrid_fwd", lambda: hybrid(False), (4 * K + 16) * B * L, "d3pm_hybrid_loss forward only, 4K+16 B/token")
             timed("q_sample", lambda: d.q_sample(x0, t), 16 * B * L,
                   "q_sample with device noise (facade call), 16 B/token")
+            smp = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
+            timed("p_sample", lambda: check(lib.d3pm_p_sample(tb.desc(), ptr(logits), K, ptr(xt), 8, ptr(t), 4, B, L, None,
+                                                              d3pm_amd._lib.NOISE_PHILOX, 1, 0, None, ptr(smp), None, sp)),
+                  (4 * K + 16) * B * L, "d3pm_p_sample (device noise, no probabilities out), 4K+16 B/token")
             t_nx = torch.empty(B, dtype=torch.int32, device=dev)
             xt_nx = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
             timed("hybrid_then_q", lambda: check(lib.d3pm_hybrid_loss_then_q_sample(
