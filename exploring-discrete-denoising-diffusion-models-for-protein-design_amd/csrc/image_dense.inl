@@ -64,10 +64,16 @@ __global__ __launch_bounds__(BLOCK) void k_dense_q_sample(ImgArgs a, const float
     float p[L::V], u[L::V];
     load_slots<L>(a.tb.qbar + ((size_t)t * K + x0) * K, g, K, 0.0f, p);
     if constexpr (NOISE == D3PM_NOISE_PHILOX) {
-      const U4 r = philox4x32_10((uint64_t)n * L::G + g, offset, seed);
-      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+      // Noise drawn on the device: nothing to match bit for bit, so the draw is one uniform per token and an inverse
+      // CDF over the weights q + eps (what the Gumbel-max over log(q + eps) samples from) -- no logarithms, one
+      // Philox call per token instead of one per four classes.
+      float w[L::V];
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) u[v] = u01(rr[v]);
+      for (int v = 0; v < L::V; ++v) w[v] = (L::VEC || L::cls(g, v) < K) ? p[v] + eps : 0.0f;
+      const U4 r = philox4x32_10((uint64_t)n, offset, seed);
+      const int pick = group_pick<L::G, L::V>(w, g, u01_open(r.x), x0, [](int gg, int vv) { return L::cls(gg, vv); });
+      if (g == 0) out[n] = pick;
+      continue;
     } else {
       load_slots<L>(noise + n * K, g, K, 0.5f, u);
     }
@@ -718,6 +724,16 @@ static int dense_q_sample(const d3pm_tables_f32* tb, const void* x0, int tok_byt
                           long npos, const float* noise, int noise_kind, uint64_t seed, uint64_t offset,
                           const uint64_t* offset_dev, int64_t* x_t, hipStream_t s) {
   const bool vec = aligned16(tb->qbar) && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise));
+  if (noise_kind == D3PM_NOISE_PHILOX && vec && tb->K == 256) {
+    // 16 lanes per token, 16-byte pieces interleaved across the group: the inverse CDF's scan stays inside a DPP row
+    // and a wave draws four tokens at a time
+    using L = Layout<16, 16, true, true>;
+    ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);
+    hipLaunchKernelGGL((k_dense_q_sample<L, D3PM_NOISE_PHILOX>), dim3(B * a.chunks), dim3(BLOCK), 0, s, a, noise, seed,
+                       offset, offset_dev, x_t);
+    D3PM_LAUNCH_CHECK("k_dense_q_sample");
+    return D3PM_OK;
+  }
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, t, t_bytes, B, npos, L::G);

@@ -959,3 +959,27 @@ def test_p_sample_flat_mixed_timesteps(pkg):
             assert freq[int(row.argmax())] == 1.0
         else:
             assert (np.abs(freq - P[i]) < 5 * np.sqrt(P[i] * (1 - P[i]) / n) + 2e-5).all(), (tv, np.abs(freq - P[i]).max())
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+def test_dense_q_sample_device_noise_distribution(pkg, bits):
+    """q_sample on dense (Gaussian) tables with noise drawn on the device: one uniform per token, inverse CDF over
+    q + eps; class frequencies against softmax(log(q + eps)).  K = 256 takes the 16-lane layout."""
+    K, T = 2 ** bits, 100
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(1e-3, 0.2, T, "linear"), transition_mat_type="gaussian",
+                              num_bits=bits, transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    assert not d.tables().structured
+    for tval, x0val in ((2, K // 3), (40, 0), (99, K - 1)):
+        B, L = 32, 8192
+        x0 = torch.full((B, L), x0val, device=DEV)
+        t = torch.full((B,), tval, dtype=torch.int32, device=DEV)
+        torch.manual_seed(21)
+        xt = d.q_sample(x0, t)
+        torch.manual_seed(21)
+        assert torch.equal(xt, d.q_sample(x0, t))
+        n = xt.numel()
+        freq = torch.bincount(xt.flatten().cpu(), minlength=K).numpy() / n
+        q = d.q_probs(x0[:1, :1], t[:1]).cpu().numpy().reshape(K).astype(np.float64) + 1e-6
+        q /= q.sum()
+        assert (np.abs(freq - q) < 5 * np.sqrt(q * (1 - q) / n) + 2e-6).all(), (bits, tval, np.abs(freq - q).max())
