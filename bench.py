@@ -543,32 +543,40 @@ def worker(args):
     progress("reverse sampling")
     reverse = None
     if samplers is not None:
-        def run_sampler(smps):
+        def run_sampler(smps, passes):
             """This rank's share of the 10 000 sequences through the 499-step loop, one HIP graph replay per
-            sub-batch."""
+            sub-batch.  The whole job is timed `passes` times back to back, every pass between a barrier and a
+            device synchronisation and taken as the slowest rank's time; the median pass is reported (at 8 ranks a
+            pass is ~3 ms per rank: one pass alone would be at the mercy of the barrier's skew)."""
             for smp in smps.values():
                 smp.sample()
             torch.cuda.synchronize()
+            times, n = [], 0
+            for _ in range(passes):
+                if use_pg:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                r0 = time.perf_counter()
+                n = 0
+                for nb in sub_sizes:
+                    if nb > 0:
+                        smps[nb].sample()
+                        n += nb
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - r0)
             if use_pg:
-                dist.barrier()
-            r0 = time.perf_counter()
-            n = 0
-            for nb in sub_sizes:
-                if nb > 0:
-                    smps[nb].sample()
-                    n += nb
-            torch.cuda.synchronize()
-            el = time.perf_counter() - r0
-            if use_pg:
-                tt_ = torch.tensor([el, float(n)], dtype=torch.float64, device=dev)
-                mx = tt_.clone()
+                mx = torch.tensor(times, dtype=torch.float64, device=dev)
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                dist.all_reduce(tt_, op=dist.ReduceOp.SUM)
-                return int(round(float(tt_[1].item()))), float(mx[0].item())
-            return n, el
+                times = mx.tolist()
+                nn_ = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+                dist.all_reduce(nn_, op=dist.ReduceOp.SUM)
+                n = int(round(float(nn_.item())))
+            times.sort()
+            return n, times[len(times) // 2], times
 
-        done, rev_el = run_sampler(samplers[0])
-        done_e2e, e2e_el = run_sampler(samplers[1])
+        REV_PASSES, E2E_PASSES = 5, 3
+        done, rev_el, rev_all = run_sampler(samplers[0], REV_PASSES)
+        done_e2e, e2e_el, _ = run_sampler(samplers[1], E2E_PASSES)
         # the reverse-step kernel alone, at the largest sub-batch of this rank
         nb = max(sub_sizes)
         xr = torch.randint(0, K_PROT, (nb, SEQ_LEN), device=dev)
@@ -589,6 +597,9 @@ def worker(args):
                            + ("launched step by step" if args.no_graph else "replayed as one HIP graph")
                            + ", path only (frozen logits)",
                    "sequences": done, "seconds": rev_el,
+                   "timing": f"median of {REV_PASSES} passes over the whole job (slowest rank per pass); "
+                             f"end to end: median of {E2E_PASSES}",
+                   "seconds_all_passes": rev_all,
                    "end_to_end_tiny_denoiser": done_e2e / e2e_el,
                    "roofline": {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": r_ach / HBM_PEAK_GBS, "kernel": "k_lvb_reverse_flat<22, 22> via "
