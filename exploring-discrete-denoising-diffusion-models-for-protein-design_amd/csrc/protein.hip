@@ -341,8 +341,13 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
 // -- every logarithm is of a ratio that is close to one wherever post_j is large.  Every class is first treated
 // as a generic one (A_j = a_off, B_j = mo_j); the classes x0 (B = mo + mdo) and x_t (A = a_diag) are corrected
 // with per-token scalars (their two logarithms in a 1 + d form, see below) and patched into the lane's own LDS row.
-// The MSA variant takes its denominator from another table (losses.py:148), for which that form does not hold: it
-// stays with the float64 kernel.  Gradient:
+// The MSA variant divides the posterior by Qbar_{t-1}[x0, x_t] instead of Qbar_t[x0, x_t] (losses.py:148): its
+// target is rho post_j with rho = Qbar_t[x0, x_t] / Qbar_{t-1}[x0, x_t], a number that depends on the timestep, on
+// the class x_t and on whether x0 == x_t only, and since the post_j sum to one its token term is
+//   sum_j rho post_j log(rho post_j / P_j) = rho (log rho + KL),
+// the gradient rho times the plain one.  rho and log rho are formed per timestep in float64 (log rho as a
+// difference of the digests' float64 logarithms: rho is close to one at late timesteps) and kept as float32 rows
+// beside the other per-timestep constants.  Gradient:
 //   gs_j = A_j cs / S2 (psum / rsum' - B_j / (den s'_j)) = g0 - g1 q_j (+ d0 at x0, + dt at x_t),  q_j = mo_j / s'_j
 //   W = sum_j gs_j mo_j,  dot = 2 (W S2 + mdo sum_i p_i^2 gs_i),  gz_i = 2 p_i^2 (W + mdo gs_i) - p_i dot.
 // The sequence sums are accumulated in float64.  Forward-only evaluation (ELBO scoring, where differences of
@@ -356,7 +361,7 @@ __device__ __forceinline__ float log2_1p(float d) {
   return fmaf(d - (w - 1.0f), 1.44269504088896340736f, __builtin_amdgcn_logf(w));
 }
 
-template <int K, int LD>
+template <int K, int LD, bool MSA>
 __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* __restrict__ pred,
                                                       const double* __restrict__ q, int tmax, int msa, float grad_scale,
                                                       double log_prior, double* __restrict__ part,
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
   extern __shared__ __align__(16) char lvb_rows[];          // [waves][64][STRIDE]
   __shared__ double red[8];
-  __shared__ float s_tab[8][5][32];                         // per wave: a_diag, a_off (Q_t), mo, den diag / off
+  // per wave: a_diag, a_off (Q_t), mo, den diag / off (Qbar_t); MSA: rho diag / off, log rho diag / off
+  __shared__ float s_tab[8][MSA ? 9 : 5][32];
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
@@ -394,15 +400,25 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   float mo[K];
   float mdo = 0, sum_mo = 0;
   if (branch == 2) {
-    const int tm = min(t - 1, a.tb.T - 1), tq = min(t, a.tb.T - 1), td = msa ? tm : tq;
-    const float vd = lane < K ? (float)dgd(a.tb.qbar_digest, tm, 0, K)[lane] : 0.0f;
-    const float vo = lane < K ? (float)dgd(a.tb.qbar_digest, tm, 1, K)[lane] : 0.0f;
+    const int tm = min(t - 1, a.tb.T - 1), tq = min(t, a.tb.T - 1);
+    const double vd64 = lane < K ? dgd(a.tb.qbar_digest, tm, 0, K)[lane] : 0.0;
+    const double vo64 = lane < K ? dgd(a.tb.qbar_digest, tm, 1, K)[lane] : 0.0;
+    const float vd = (float)vd64, vo = (float)vo64;
     if (lane < K) {
+      const double dd = dgd(a.tb.qbar_digest, tq, 0, K)[lane], dof = dgd(a.tb.qbar_digest, tq, 1, K)[lane];
       s_tab[wave][0][lane] = (float)dgd(a.tb.qone_digest, tq, 0, K)[lane];
       s_tab[wave][1][lane] = (float)dgd(a.tb.qone_digest, tq, 1, K)[lane];
       s_tab[wave][2][lane] = vo;
-      s_tab[wave][3][lane] = (float)dgd(a.tb.qbar_digest, td, 0, K)[lane];
-      s_tab[wave][4][lane] = (float)dgd(a.tb.qbar_digest, td, 1, K)[lane];
+      s_tab[wave][3][lane] = (float)dd;
+      s_tab[wave][4][lane] = (float)dof;
+      if constexpr (MSA) {
+        // rho = Qbar_t[x0, x_t] / Qbar_{t-1}[x0, x_t] for x0 == x_t (diagonal) and x0 != x_t; a pair that
+        // Qbar_{t-1} gives no weight never occurs (x_t was drawn from it), its rho is left at zero
+        s_tab[wave][5][lane] = vd64 > 0.0 ? (float)(dd * rcp64(vd64)) : 0.0f;
+        s_tab[wave][6][lane] = vo64 > 0.0 ? (float)(dof * rcp64(vo64)) : 0.0f;
+        s_tab[wave][7][lane] = vd64 > 0.0 ? (float)(dgd(a.tb.qbar_digest, tq, 2, K)[lane] - dgd(a.tb.qbar_digest, tm, 2, K)[lane]) : 0.0f;
+        s_tab[wave][8][lane] = vo64 > 0.0 ? (float)(dgd(a.tb.qbar_digest, tq, 3, K)[lane] - dgd(a.tb.qbar_digest, tm, 3, K)[lane]) : 0.0f;
+      }
     }
     mdo = lane_broadcast(vd - vo, 0);
     sum_mo = wave_sum(lane < K ? vo : 0.0f);
@@ -518,11 +534,16 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         kl = fmaf(a_x0 * b_x0, lb_x0, kl);
         kl = fmaf((1.0f - same) * da * mo_xt, lg_xt, kl);
         tok_loss = kl * iden * LN2;                                  // logarithms above are base 2
+        float rho = 1.0f;
+        if constexpr (MSA) {
+          rho = same_b ? s_tab[wave][5][xt] : s_tab[wave][6][xt];
+          tok_loss = rho * ((same_b ? s_tab[wave][7][xt] : s_tab[wave][8][xt]) + tok_loss);
+        }
         // gradient
         const float b_xt = fmaf(same, mdo, mo_xt);
         const float psum = iden * fmaf(a_o, sum_mo + mdo, da * b_xt);
         const float iS2 = __builtin_amdgcn_rcpf(S2), irs = __builtin_amdgcn_rcpf(rs);
-        const float k = cs * iS2;
+        const float k = (MSA ? cs * rho : cs) * iS2;
         const float g0 = a_o * k * psum * irs, g1 = a_o * k * iden;
         const float gx0 = a_x0 * k * (psum * irs - b_x0 * iden * r_x0);          // exact gs at x0
         const float d0 = gx0 - (g0 - g1 * mo_x0 * r_x0);
@@ -1044,10 +1065,11 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
   hipStream_t s = (hipStream_t)stream;
   // sample_prior builds a float32 1/K and takes its float32 log (losses.py:11-12,60)
   const double log_prior = (double)logf(1.0f / (float)tb->K);
-  // training form: one token per lane, float32 (K = 22 with rows of 22 or 24 logits, the two alphabets of the
-  // reference's denoisers); everything else, and forward-only evaluation, on the float64 kernel
+  // training form (both D3PMLVBLoss and its MSA variant): one token per lane, float32 (K = 22 with rows of 22 or
+  // 24 logits, the two alphabets of the reference's denoisers); every other shape, and forward-only evaluation,
+  // on the float64 kernel
   static const bool allow_tpl = !(getenv("D3PM_LVB_F64") && atoi(getenv("D3PM_LVB_F64")));
-  if (allow_tpl && dpred && msa == 0 && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+  if (allow_tpl && dpred && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
       ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
     int block;
@@ -1067,9 +1089,9 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       const size_t need = (size_t)B * a.chunks * sizeof(double);
       D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     }
-    auto go = [&](auto ldc) -> int {
+    auto go = [&](auto ldc, auto msac) -> int {
       constexpr int LDC = decltype(ldc)::value;
-      auto kern = k_lvb_loss_tpl<22, LDC>;
+      auto kern = k_lvb_loss_tpl<22, LDC, decltype(msac)::value>;
       const size_t sh = (size_t)(block / 64) * RowImage<LDC>::BYTES;
       if (sh > 48 * 1024) {
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -1080,7 +1102,10 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       D3PM_LAUNCH_CHECK("k_lvb_loss_tpl");
       return D3PM_OK;
     };
-    const int rc = ld == 22 ? go(std::integral_constant<int, 22>{}) : go(std::integral_constant<int, 24>{});
+    using I22 = std::integral_constant<int, 22>;
+    using I24 = std::integral_constant<int, 24>;
+    const int rc = msa > 0 ? (ld == 22 ? go(I22{}, std::true_type{}) : go(I24{}, std::true_type{}))
+                           : (ld == 22 ? go(I22{}, std::false_type{}) : go(I24{}, std::false_type{}));
     if (rc) return rc;
     if (a.chunks > 1) {
       hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);

@@ -179,6 +179,43 @@ def test_lvb_loss_msa_golden(pkg, tables500):
     np.testing.assert_allclose(gr.cpu().numpy(), g["grad"], rtol=1e-5, atol=GRAD_FLOOR * np.abs(g["grad"]).max())
 
 
+@pytest.mark.parametrize("n_tok,B,D,L", [(22, 8, 3, 50), (24, 8, 4, 64), (24, 200, 2, 37)])
+def test_lvb_loss_msa_against_oracle(pkg, tables500, n_tok, B, D, L):
+    """D3PMLVBLossMSA's training form (float32 kernel: rho (log rho + KL) per token) against the CPU oracle:
+    per-sequence losses and the gradient, early and late timesteps, the t == 1 and t == tmax branches, position
+    counts that are no multiple of a wave, a chunked launch (B = 8) and one workgroup per element (B = 200)."""
+    from d3pm_amd._ops import ops
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    gen = torch.Generator().manual_seed(5 + n_tok + B)
+    x0 = torch.randint(0, 22, (B, D, L), generator=gen)
+    ts = torch.randint(2, 500, (B,), generator=gen)
+    ts[:8] = torch.tensor([1, 2, 3, 17, 250, 499, 500, 2])
+    Qb_c, Qt_c = Qb.cpu(), Qt.cpu()
+    # x_t drawn from the forward process, so that every (x0, x_t) pair has weight under Qbar_{t-1} too
+    rows = Qb_c[(ts - 1).clamp(max=499)][:, None, None].expand(B, D, L, 22, 22)
+    probs = torch.gather(rows, 3, x0[..., None, None].expand(B, D, L, 1, 22))[..., 0, :]
+    x_t = torch.multinomial(probs.reshape(-1, 22), 1, generator=gen).reshape(B, D, L)
+    q = torch.softmax(torch.randn(B, D, L, 22, generator=gen, dtype=torch.float64), -1)
+    pred = torch.randn(B, D, L, n_tok, generator=gen) * 2.0
+    pr_ref = pred.clone().requires_grad_(True)
+    per_ref = pr.lvb_per_sequence(pr.one_hot(x_t, 22), q, pr_ref, x0, pr.one_hot(x0, 22), ts, Qt_c, Qb_c,
+                                  K=22, tmax=500, msa=True)
+    baked = float(np.float32(1.0) / np.float32(B))
+    (per_ref.sum() * baked).backward()
+    tb = protein_tables(Qt, Qb)
+    per, dp = ops.lvb_loss(*tb.op_args(), pred.to(DEV).reshape(B, D * L, n_tok).contiguous(), x0.to(DEV), x_t.to(DEV),
+                           ts.to(DEV), q.to(DEV), 500, D, baked, True)
+    np.testing.assert_allclose(per.cpu().numpy(), per_ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    ref = pr_ref.grad.numpy().reshape(B, D * L, n_tok)
+    np.testing.assert_allclose(dp.cpu().numpy().reshape(ref.shape), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+    # and through the reference-shaped module
+    pm = pred.to(DEV).requires_grad_(True)
+    lvb = pkg.D3PMLVBLossMSA(tmax=500, tokenizer=tok)(None, q.to(DEV), pm, x0.to(DEV), None, ts.to(DEV), Qt, Qb,
+                                                      src=x_t.to(DEV))
+    np.testing.assert_allclose(float(lvb.detach()), float(per_ref.detach().sum() / B), rtol=1e-5)
+
+
 def test_generate_replay_golden(pkg):
     g = golden("protein_generate")
     tok = pkg.Tokenizer()

@@ -118,6 +118,11 @@ def main():
     corrupt()
     timed("corrupt", corrupt, 16 * BP * LP, "d3pm_corrupt (device noise), 16 B/token")
     timed("lvb", lvb, (8 * LDP + 16) * BP * LP, "d3pm_lvb_loss fwd+bwd, n_tokens=24, 8 ld+16 B/token")
+
+    def lvb_msa():          # the same tokens taken as MSAs of depth 8 (D3PMLVBLossMSA: msa = depth)
+        check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 8,
+                                1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
+    timed("lvb_msa", lvb_msa, (8 * LDP + 16) * BP * LP, "d3pm_lvb_loss fwd+bwd, MSA variant (depth 8 x 64), n_tokens=24, 8 ld+16 B/token")
     NB, SL = 1250, 263
     for ld in (22, 24):
         xr = torch.randint(0, KP, (NB, SL), device=dev)
