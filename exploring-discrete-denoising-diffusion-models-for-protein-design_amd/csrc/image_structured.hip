@@ -2058,6 +2058,23 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
     D3PM_LAUNCH_CHECK("k_p_sample_flat");
     return D3PM_OK;
   }
+  static const bool allow_rows = !(getenv("D3PM_PSAMPLE_ROWS") && !atoi(getenv("D3PM_PSAMPLE_ROWS")));
+  if (allow_rows && noise_kind == D3PM_NOISE_PHILOX && !probs && vec && (tb->K == 64 || tb->K == 128 || tb->K == 256)) {
+    // the sampling loop's call at K = 64 / 128 / 256: a token on 8 or 16 lanes (8 or 16 classes a lane, interleaved
+    // 16-byte pieces) instead of 16 / 32 / 64, so that the softmax reductions, the prefix scan of the draw and its
+    // search stay inside one DPP row and a wave takes 4 or 8 tokens per pass
+    auto rows = [&](auto lay) {
+      using L = decltype(lay);
+      ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, L::G);
+      hipLaunchKernelGGL((k_p_sample<L, D3PM_NOISE_PHILOX>), dim3(B * a.chunks), dim3(BLOCK), 0, s, a, logits, ld, noise,
+                         seed, offset, offset_dev, sample, probs);
+      D3PM_LAUNCH_CHECK("k_p_sample");
+      return D3PM_OK;
+    };
+    if (tb->K == 256) return rows(Layout<16, 16, true, true>{});
+    if (tb->K == 128) return rows(Layout<16, 8, true, true>{});
+    return rows(Layout<8, 8, true, true>{});
+  }
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, L::G);

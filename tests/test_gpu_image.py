@@ -503,6 +503,46 @@ def test_p_sample_device_noise_distribution(pkg, kind, bits):
             assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
 
 
+@pytest.mark.parametrize("kind,bits", [("uniform", 8), ("absorbing", 8), ("uniform", 7), ("absorbing", 6)])
+def test_p_sample_device_noise_structured_wide_alphabets(pkg, kind, bits):
+    """The sampling loop's call (device noise, no probabilities out) on structured tables with 64 / 128 / 256
+    classes, where a token sits on 8 or 16 lanes: class frequencies over many identical tokens against the softmax
+    of the parity-tested posterior logits (a different timestep per batch element), the same draws under the same
+    generator state, and the noise-free argmax of the logits at t = 0 on random rows."""
+    K, T, B, L = 2 ** bits, 50, 8, 16384
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type=kind, num_bits=bits,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    assert d.tables().structured
+    gen = torch.Generator().manual_seed(40 + bits)
+    row = (2.0 * torch.randn(K, generator=gen)).to(DEV)
+    logits = row.expand(B, L, 1, 1, K).contiguous()
+    x_t = torch.full((B, L, 1, 1), K // 3, device=DEV)
+    if kind == "absorbing":
+        x_t[4:] = K // 2                                           # the mask class
+    t = torch.tensor([1, 2, 7, 20, 33, 49, 10, 5], dtype=torch.int32, device=DEV)
+    post = d.q_posterior_logits(logits[:, :1], x_t[:, :1], t, x_start_logits=True)
+    P = torch.softmax(post.double(), -1).reshape(B, K).cpu().numpy()
+    out = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        out.append(d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False)[0])
+    assert torch.equal(out[0], out[1])
+    assert int(out[0].min()) >= 0 and int(out[0].max()) < K
+    for b in range(B):
+        freq = torch.bincount(out[0][b].flatten().cpu(), minlength=K).numpy() / L
+        tol = 5 * np.sqrt(P[b] * (1 - P[b]) / L) + 2e-4
+        assert (np.abs(freq - P[b]) < tol).all(), (b, int(t[b]), np.abs(freq - P[b]).max())
+    # t = 0: argmax of the logits, first maximum, ragged position count
+    lg = torch.randn(3, 77, 1, 1, K, generator=gen).to(DEV)
+    lg[1, 5, 0, 0, 7] = lg[1, 5, 0, 0, K - 2] = 50.0               # a tie: the first index wins
+    xz = torch.randint(0, K, (3, 77, 1, 1), generator=gen).to(DEV)
+    tz = torch.tensor([0, 0, 3], dtype=torch.int32, device=DEV)
+    sz = d._p_sample_from_logits(lg, xz, tz, None, "uniform", want_probs=False)[0]
+    assert torch.equal(sz[:2].cpu(), lg[:2].cpu().argmax(-1))
+    assert int(sz[1, 5, 0, 0]) == 7
+
+
 def test_raw_ctypes_binding_as_documented(pkg):
     """The binding a maintainer of the reference would write (plain ctypes, no
     helper of this package): digests from the float64 tables, then the fused loss
