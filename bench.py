@@ -673,9 +673,9 @@ def worker(args):
                            "gradient, B=256 L=512 K=22 n_tokens=24, back-to-back launches",
                "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": l_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24> via d3pm_lvb_loss, back-to-back launches "
+                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24, false> via d3pm_lvb_loss, back-to-back launches "
                             "between two HIP events", "kernel_ms": lk_ms, "algorithmic_bytes_per_token": lbytes,
-                            "traffic": measured_traffic("k_lvb_loss_tpl")}}
+                            "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false>")}}
 
     progress("sections done")
     if rank == 0:
