@@ -248,11 +248,12 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
       }
     } else if (branch == 1) {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60)
+      // (no probabilities given: the element's loss is NaN, nothing is read)
       double qq[L::V];
-      load_slots<L>(q + n * K, g, K, 0.0, qq);
-      double s = 0;
+      if (q) load_slots<L>(q + n * K, g, K, 0.0, qq);
+      double s = q ? 0.0 : (double)NAN;
 #pragma unroll
-      for (int v = 0; v < L::V; ++v) s += (qq[v] > 0.0 ? qq[v] * log(qq[v]) : 0.0) - qq[v] * log_prior;
+      for (int v = 0; v < L::V; ++v) s += q ? (qq[v] > 0.0 ? qq[v] * log(qq[v]) : 0.0) - qq[v] * log_prior : 0.0;
       // 'batchmean' divides by the leading size of q[i]: L for a sequence (what the
       // finalize step does), but only the depth D for an MSA laid out [D,L,K]
       tok_loss = group_sum<L::G>(s) * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
@@ -436,7 +437,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     float tok_loss = 0, add0 = 0, addt = 0;
     if (branch == 1) {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
-      if (live) {
+      if (live && !q) acc = (double)NAN;                       // no probabilities given: NaN, nothing is read
+      if (live && q) {
         const double* qq = q + ((size_t)b * a.npos + base + lane) * K;
         double s = 0;
         for (int j = 0; j < K; ++j) s += (qq[j] > 0.0 ? qq[j] * log(qq[j]) : 0.0) - qq[j] * log_prior;

@@ -303,7 +303,8 @@ size_t d3pm_lvb_loss_workspace(int B, long npos, int K);
  * t==tmax term is normalised by D, the leading size of q[i] (:130).  Also the gradient of
  * grad_scale * sum_b per_seq[b] with respect to the predictions.
  *   pred float32 [B,npos,ld], ld = n_tokens >= K (t==1 branch uses all ld)
- *   q    float64 [B,npos,K] forward probabilities, read only where t==tmax
+ *   q    float64 [B,npos,K] forward probabilities, read only where t==tmax; may be
+ *        NULL, and then an element with t==tmax gets per_seq = NaN (nothing is read)
  *   per_seq float64 [B];  dpred float32 [B,npos,ld] or NULL
  *   workspace: d3pm_lvb_loss_workspace() bytes, contents irrelevant. */
 int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,

@@ -216,6 +216,25 @@ def test_lvb_loss_msa_against_oracle(pkg, tables500, n_tok, B, D, L):
     np.testing.assert_allclose(float(lvb.detach()), float(per_ref.detach().sum() / B), rtol=1e-5)
 
 
+@pytest.mark.parametrize("want_grad", [False, True])
+def test_lvb_loss_without_q(pkg, tables500, want_grad):
+    """q = None (the collaters' lean form): an element at t == tmax has no probabilities to read and gets NaN, every
+    other element its loss -- no read through the null pointer (float64 evaluation kernel and float32 training
+    kernel)."""
+    tok, Qb, Qt = tables500
+    gen = torch.Generator().manual_seed(8)
+    x0 = torch.randint(0, 22, (6, 70), generator=gen).to(DEV)
+    x_t = torch.randint(0, 22, (6, 70), generator=gen).to(DEV)
+    ts = torch.tensor([500, 1, 2, 250, 499, 500], device=DEV)
+    pred = torch.randn(6, 70, 24, generator=gen).to(DEV).requires_grad_(want_grad)
+    per = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, evaluation=True)(None, None, pred, x0, None, ts, Qt, Qb, src=x_t)
+    per = per.detach().cpu().numpy()
+    assert np.isnan(per[[0, 5]]).all() and np.isfinite(per[1:5]).all(), per
+    q = torch.softmax(torch.randn(6, 70, 22, generator=gen, dtype=torch.float64), -1).to(DEV)
+    full = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, evaluation=True)(None, q, pred, x0, None, ts, Qt, Qb, src=x_t)
+    np.testing.assert_allclose(per[1:5], full.detach().cpu().numpy()[1:5], rtol=1e-12 if not want_grad else 1e-5)
+
+
 def test_generate_replay_golden(pkg):
     g = golden("protein_generate")
     tok = pkg.Tokenizer()
