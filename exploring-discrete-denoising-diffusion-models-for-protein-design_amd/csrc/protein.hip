@@ -1075,7 +1075,12 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
     int block;
-    if (B >= 192) {
+    // The kernel holds 168 registers a lane: three waves per SIMD.  About one batch element per CU: one workgroup
+    // of up to eight waves per element (two per SIMD, every wave a single pass).  Larger batches: 256-thread
+    // workgroups, three of them resident per CU (a 512-thread workgroup leaves no room for a second one), each wave
+    // walking its chunk pass by pass with the next rows requested ahead.  Smaller batches: 256-thread chunks.
+    static const int lvb_one_wg_max = getenv("D3PM_LVB_ONE_WG_MAX") ? atoi(getenv("D3PM_LVB_ONE_WG_MAX")) : 320;
+    if (B >= 192 && B <= lvb_one_wg_max) {
       const long want = ((npos + 63) / 64) * 64;
       block = (int)(want > 512 ? 512 : want);
       a.chunks = 1;

@@ -216,6 +216,36 @@ def test_lvb_loss_msa_against_oracle(pkg, tables500, n_tok, B, D, L):
     np.testing.assert_allclose(float(lvb.detach()), float(per_ref.detach().sum() / B), rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,L", [(1030, 270), (400, 263)])
+def test_lvb_loss_large_batch_against_oracle(pkg, tables500, B, L):
+    """Batches beyond one workgroup per CU run the training kernel in 256-thread workgroups whose waves walk
+    several passes (B = 1030: one chunk of two passes, the second ragged) or in chunks summed by a second launch
+    (B = 400): per-sequence losses and the gradient against the CPU oracle."""
+    from d3pm_amd._ops import ops
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    gen = torch.Generator().manual_seed(B)
+    x0 = torch.randint(0, 22, (B, L), generator=gen)
+    ts = torch.randint(1, 501, (B,), generator=gen)
+    ts[:4] = torch.tensor([1, 2, 500, 499])
+    Qb_c, Qt_c = Qb.cpu(), Qt.cpu()
+    probs = Qb_c[(ts - 1).clamp(max=499)][torch.arange(B)[:, None], x0]                   # [B, L, K]
+    x_t = torch.multinomial(probs.reshape(-1, 22), 1, generator=gen).reshape(B, L)
+    q = torch.softmax(torch.randn(B, L, 22, generator=gen, dtype=torch.float64), -1)
+    pred = torch.randn(B, L, 24, generator=gen) * 2.0
+    pr_ref = pred.clone().requires_grad_(True)
+    per_ref = pr.lvb_per_sequence(pr.one_hot(x_t, 22), q, pr_ref, x0, pr.one_hot(x0, 22), ts, Qt_c, Qb_c,
+                                  K=22, tmax=500)
+    baked = float(np.float32(1.0) / np.float32(B))
+    (per_ref.sum() * baked).backward()
+    tb = protein_tables(Qt, Qb)
+    per, dp = ops.lvb_loss(*tb.op_args(), pred.to(DEV), x0.to(DEV), x_t.to(DEV), ts.to(DEV), q.to(DEV), 500, 0, baked,
+                           True)
+    np.testing.assert_allclose(per.cpu().numpy(), per_ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    ref = pr_ref.grad.numpy()
+    np.testing.assert_allclose(dp.cpu().numpy(), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("want_grad", [False, True])
 def test_lvb_loss_without_q(pkg, tables500, want_grad):
     """q = None (the collaters' lean form): an element at t == tmax has no probabilities to read and gets NaN, every

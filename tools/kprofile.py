@@ -134,6 +134,41 @@ def main():
             check(lib.d3pm_lvb_reverse_step(ptab.desc(), ptr(frz), ld, ptr(xr), ptr(tr), NB, SL, None, 7, 0, None, 1.0,
                                             0, ptr(outr), sp))
         timed(f"reverse_{ld}", rev, (4 * ld + 16) * NB * SL, f"d3pm_lvb_reverse_step (device noise), n_tokens={ld}, 4 ld+16 B/token")
+    # ---- the same two losses at eight times the batch (the global batch of 2048 on one GPU: 1 M tokens, 285 / 218 MB
+    # per launch, more than the 256 MiB Infinity Cache holds): what the kernels reach once the launch overhead and
+    # the arrival of the first rows are a small part of the launch
+    if not only or only & {"hybrid_b2048", "lvb_b2048"}:
+        BB = 2048
+        x0b = torch.randint(0, K, (BB, L, 1, 1), device=dev)
+        lgb = torch.randn(BB, L, 1, 1, K, device=dev)
+        dlb = torch.empty_like(lgb)
+        lossb = torch.empty(BB, device=dev)
+        tbig = torch.randint(0, T, (BB,), dtype=torch.int32, device=dev)
+        wsbb = lib.d3pm_hybrid_loss_workspace(BB, L, K)
+        wsb_ = torch.empty(max(wsbb // 4, 1), device=dev)
+        du = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=5, transition_bands=None,
+                                        model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                        hybrid_coeff=lam, device=dev)
+        tbu = du.tables()
+        xtb = du.q_sample(x0b, tbig)
+        timed("hybrid_b2048", lambda: check(lib.d3pm_hybrid_loss(
+            tbu.desc(), ptr(lgb), K, ptr(x0b), 8, ptr(xtb), 8, ptr(tbig), 4, BB, L, LOSS["hybrid"], lam, 1.0 / BB, None,
+            None, None, ptr(lossb), ptr(dlb), None, None, 0, ptr(wsb_), wsbb, sp)),
+            (8 * K + 16) * BB * L, "d3pm_hybrid_loss fwd+bwd, uniform Q, B=2048 L=512 K=32")
+        del lgb, dlb
+        x0q = torch.randint(0, KP, (BB, LP), device=dev)
+        tq = torch.randint(2, 500, (BB,), device=dev)
+        xtq = torch.empty_like(x0q)
+        check(lib.d3pm_corrupt(ptab.desc(), ptr(x0q), ptr(tq), BB, LP, None, 1, 0, ptr(xtq), None, sp))
+        predq = torch.randn(BB, LP, LDP, device=dev)
+        dpq = torch.empty_like(predq)
+        perq = torch.empty(BB, dtype=torch.float64, device=dev)
+        wsbq = lib.d3pm_lvb_loss_workspace(BB, LP, KP)
+        wsq = torch.empty(max(wsbq // 8, 1), dtype=torch.float64, device=dev)
+        timed("lvb_b2048", lambda: check(lib.d3pm_lvb_loss(
+            ptab.desc(), ptr(predq), LDP, ptr(x0q), ptr(xtq), ptr(tq), None, BB, LP, 500, 0, 1.0 / BB, ptr(perq),
+            ptr(dpq), ptr(wsq), wsbq, sp)),
+            (8 * LDP + 16) * BB * LP, "d3pm_lvb_loss fwd+bwd, n_tokens=24, B=2048 L=512")
     print(json.dumps(rows))
 
 
