@@ -1331,8 +1331,9 @@ __global__ void k_loss_finalize(LossOut out, int B, int chunks, long npos, int l
 }
 
 // ------------------------------------------------------------------ p_sample
+// (with 16 classes a lane the kernel would take 149 registers, three waves per SIMD: held to 128, without spills)
 template <class L, int NOISE>
-__global__ __launch_bounds__(BLOCK) void k_p_sample(ImgArgs a, const float* __restrict__ logits, long ld,
+__global__ __launch_bounds__(BLOCK, L::V >= 16 ? 4 : 1) void k_p_sample(ImgArgs a, const float* __restrict__ logits, long ld,
                                                     const float* __restrict__ noise, uint64_t seed, uint64_t offset,
                                                     const uint64_t* __restrict__ offset_dev,
                                                     int64_t* __restrict__ sample, float* __restrict__ probs) {
