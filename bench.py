@@ -677,6 +677,56 @@ def worker(args):
                             "between two HIP events", "kernel_ms": lk_ms, "algorithmic_bytes_per_token": lbytes,
                             "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false>")}}
 
+    # ---- secondary: the two loss kernels at eight times the batch (B = 2048: the global batch of the DDP
+    # configuration on one GPU; 285 / 218 MB per launch, more than the 256 MiB Infinity Cache holds), where launch
+    # overhead and the arrival of the first rows are a small part of the launch
+    progress("large batch")
+    large = None
+    if rank == 0 and not args.no_secondary:
+        BB = 2048
+        x0b = torch.randint(0, K, (BB, L, 1, 1), device=dev)
+        tbg = torch.randint(0, T, (BB,), dtype=torch.int32, device=dev)
+        xtb = d.q_sample(x0b, tbg)
+        lgb = torch.randn(BB, L, 1, 1, K, device=dev)
+        dlb = torch.empty_like(lgb)
+        lsb = torch.empty(BB, device=dev)
+        wsbb = lib.d3pm_hybrid_loss_workspace(BB, L, K)
+        wsb_ = torch.empty(max(wsbb // 4, 1), device=dev)
+        tbd = d.tables()
+
+        def big_hybrid():
+            check(lib.d3pm_hybrid_loss(tbd.desc(), ptr(lgb), K, ptr(x0b), 8, ptr(xtb), 8, ptr(tbg), 4, BB, L,
+                                       LOSS["hybrid"], LAMBDA, 1.0 / BB, None, None, None, ptr(lsb), ptr(dlb), None, None, 0,
+                                       ptr(wsb_), wsbb, sp))
+        bh_ms = event_ms(big_hybrid, 50, warm=5)
+        del lgb, dlb
+        BPb, LPb, KPb, LDPb = BB, 512, 22, 24
+        x0q = torch.randint(0, KPb, (BPb, LPb), device=dev)
+        tq = torch.randint(2, 500, (BPb,), device=dev)
+        xtq = torch.empty_like(x0q)
+        check(lib.d3pm_corrupt(ptab.desc(), ptr(x0q), ptr(tq), BPb, LPb, None, 1, 0, ptr(xtq), None, sp))
+        pq = torch.randn(BPb, LPb, LDPb, device=dev)
+        dq = torch.empty_like(pq)
+        perq = torch.empty(BPb, dtype=torch.float64, device=dev)
+        wsbq = lib.d3pm_lvb_loss_workspace(BPb, LPb, KPb)
+        wsq = torch.empty(max(wsbq // 8, 1), dtype=torch.float64, device=dev)
+
+        def big_lvb():
+            check(lib.d3pm_lvb_loss(ptab.desc(), ptr(pq), LDPb, ptr(x0q), ptr(xtq), ptr(tq), None, BPb, LPb, 500, 0,
+                                    1.0 / BPb, ptr(perq), ptr(dq), ptr(wsq), wsbq, sp))
+        bl_ms = event_ms(big_lvb, 50, warm=5)
+        del pq, dq
+
+        def roof(bytes_per_token, ntok, ms, kernel):
+            ach = bytes_per_token * ntok / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_token": bytes_per_token,
+                    "tokens_per_launch": ntok}
+        large = {"workload": f"the two loss kernels at B={BB}, L=512 (1 048 576 tokens per launch), back-to-back launches "
+                             "between two HIP events",
+                 "hybrid_loss": roof(BYTES_PER_TOKEN, BB * L, bh_ms, "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss"),
+                 "lvb_loss": roof(8 * LDPb + 16, BPb * LPb, bl_ms, "k_lvb_loss_tpl<22, 24, false> via d3pm_lvb_loss")}
+
     progress("sections done")
     if rank == 0:
         achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
@@ -724,6 +774,7 @@ def worker(args):
             "reverse_sample": reverse,
             "image_k256": dense,
             "protein_lvb": lvb,
+            "large_batch": large,
         }
         if world == 1 and not args.no_cpu_baseline:
             head, lvb_cpu, rev_cpu = cpu_baselines()

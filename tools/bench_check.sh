@@ -19,5 +19,9 @@ for k in ("absorbing", "reverse_sample", "image_k256", "protein_lvb"):
     if s:
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in s.items() if a in ("value", "ms_per_step", "kernel_ms", "end_to_end_tiny_denoiser", "tokens_per_s")},
               "frac %.3f" % s["roofline"]["frac"], "cpu", (s.get("cpu_baseline") or {}).get("value"))
+lb = d.get("large_batch")
+if lb:
+    print("large_batch hybrid %.2f us frac %.3f   lvb %.2f us frac %.3f" % (
+        lb["hybrid_loss"]["kernel_ms"] * 1e3, lb["hybrid_loss"]["frac"], lb["lvb_loss"]["kernel_ms"] * 1e3, lb["lvb_loss"]["frac"]))
 print("cpu_baseline", d.get("cpu_baseline"))
 P
