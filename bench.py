@@ -724,7 +724,7 @@ def worker(args):
                     "tokens_per_launch": ntok}
         large = {"workload": f"the two loss kernels at B={BB}, L=512 (1 048 576 tokens per launch), back-to-back launches "
                              "between two HIP events",
-                 "hybrid_loss": roof(BYTES_PER_TOKEN, BB * L, bh_ms, "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss"),
+                 "hybrid_loss": roof(BYTES_PER_TOKEN, BB * L, bh_ms, "k_hybrid_loss_tpl<32, true, 512> in 256-thread workgroups via d3pm_hybrid_loss"),
                  "lvb_loss": roof(8 * LDPb + 16, BPb * LPb, bl_ms, "k_lvb_loss_tpl<22, 24, false> via d3pm_lvb_loss")}
 
     progress("sections done")

@@ -1896,14 +1896,26 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
     // one token per lane
     ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, 1);
     int block;
-    if (B >= 192) {
+    // Up to one batch element per CU (256 of them), or a batch that nearly fills a second round of the CUs: one
+    // workgroup per element (the pair kernel at K = 32).  Other batches above 256: the token-per-lane kernel in
+    // 256-thread workgroups, three of them resident per CU at its 153 registers and out of step with each other,
+    // each wave walking its chunk pass by pass with the next rows requested ahead.  K = 32, L = 512, one workgroup
+    // per element against 256-thread workgroups: B = 320 11.9 / 9.8 us, 384 13.4 / 10.7, 448 12.3 / 15.0,
+    // 512 13.9 / 14.2, 768 20.3 / 18.6, 2048 50.6 / 44.9 (0.70 / 0.79 of the HBM roofline: a 1024-thread workgroup
+    // fills a CU alone and loads, computes and stores in lock step).
+    static const char* one_wg_env = getenv("D3PM_LOSS_ONE_WG_MAX");
+    static const int one_wg_max = one_wg_env ? atoi(one_wg_env) : 256;
+    const bool one_wg = B >= 192 && (B <= one_wg_max || (!one_wg_env && B >= 432 && B <= 512));
+    if (one_wg) {
       const long want = ((npos + 63) / 64) * 64;
       block = (int)(want > 512 ? 512 : want);      // (1024 threads leave 128 registers a lane: spills)
       a.chunks = 1;
       a.chunk_pos = npos;
     } else {
       block = 256;
-      const TokenGrid tg = token_grid(B, npos, block, 1024);
+      // (large batches: one chunk per element as soon as that gives two workgroups per CU -- no second launch)
+      static const int big_target = getenv("D3PM_BIG_TARGET") ? atoi(getenv("D3PM_BIG_TARGET")) : 512;
+      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : 1024);
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }
@@ -1913,7 +1925,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       o.part = partials;
     }
     static const int pair = getenv("D3PM_LOSS_PAIR") ? atoi(getenv("D3PM_LOSS_PAIR")) : 1;   // 0: one token per lane
-    if (pair && K == 32 && a.chunks == 1) {
+    if (pair && K == 32 && a.chunks == 1 && one_wg) {
       // two lanes per token: 32 tokens per wave, up to 16 waves per workgroup
       const long waves = (npos + 31) / 32;
       const int pblock = (int)(waves > 16 ? 16 : waves) * 64;

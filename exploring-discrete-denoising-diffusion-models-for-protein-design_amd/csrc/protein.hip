@@ -1075,11 +1075,13 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
     int block;
-    // The kernel holds 168 registers a lane: three waves per SIMD.  About one batch element per CU: one workgroup
+    // The kernel holds 168 registers a lane: three waves per SIMD.  Up to one batch element per CU: one workgroup
     // of up to eight waves per element (two per SIMD, every wave a single pass).  Larger batches: 256-thread
     // workgroups, three of them resident per CU (a 512-thread workgroup leaves no room for a second one), each wave
-    // walking its chunk pass by pass with the next rows requested ahead.  Smaller batches: 256-thread chunks.
-    static const int lvb_one_wg_max = getenv("D3PM_LVB_ONE_WG_MAX") ? atoi(getenv("D3PM_LVB_ONE_WG_MAX")) : 320;
+    // walking its chunk pass by pass with the next rows requested ahead (L = 512, one workgroup per element against
+    // 256-thread workgroups: B = 320 12.5 / 11.4 us, 512 14.0 / 12.1, 768 23.9 / 18.2, 2048 60.8 / 40.6).  Smaller
+    // batches: 256-thread chunks.
+    static const int lvb_one_wg_max = getenv("D3PM_LVB_ONE_WG_MAX") ? atoi(getenv("D3PM_LVB_ONE_WG_MAX")) : 256;
     if (B >= 192 && B <= lvb_one_wg_max) {
       const long want = ((npos + 63) / 64) * 64;
       block = (int)(want > 512 ? 512 : want);
@@ -1087,7 +1089,9 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       a.chunk_pos = npos;
     } else {
       block = 256;
-      const TokenGrid tg = token_grid(B, npos, block, 1024);
+      // (large batches: one chunk per element as soon as that gives two workgroups per CU -- no second launch)
+      static const int big_target = getenv("D3PM_BIG_TARGET") ? atoi(getenv("D3PM_BIG_TARGET")) : 512;
+      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : 1024);
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }

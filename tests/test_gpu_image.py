@@ -262,12 +262,13 @@ def _oracle_process(betas, kind, K, lam):
 
 
 @pytest.mark.parametrize("K", [8, 16, 24, 32])
-@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (1, 64), (192, 1100)])
+@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (1, 64), (192, 1100), (300, 70), (600, 300), (450, 40)])
 def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
     """The fused loss kernels that give a lane a whole token (structured tables, K in {8, 16, 24, 32}, rows 16-byte
     aligned) or, for K = 32 with one workgroup per batch element (B >= 192), a pair of lanes: ragged last wave,
-    several rounds per workgroup, chunked small batches and one workgroup per batch element, t = 0 rows, weighted
-    upstream gradient -- against the CPU oracle; K = 24 through the C ABI on tables passed in (the facade only
+    several rounds per workgroup, chunked small batches and one workgroup per batch element, batches beyond one
+    element per CU (B = 300, 600: 256-thread workgroups whose waves walk several passes; B = 450: a second round of
+    one workgroup per element), t = 0 rows, weighted upstream gradient -- against the CPU oracle; K = 24 through the C ABI on tables passed in (the facade only
     builds K = 2 ** num_bits)."""
     from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
     from d3pm_amd.tables import ImageTables
