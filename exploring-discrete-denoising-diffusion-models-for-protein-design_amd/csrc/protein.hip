@@ -1091,7 +1091,8 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
       block = 256;
       // (large batches: one chunk per element as soon as that gives two workgroups per CU -- no second launch)
       static const int big_target = getenv("D3PM_BIG_TARGET") ? atoi(getenv("D3PM_BIG_TARGET")) : 512;
-      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : 1024);
+      static const int small_target = getenv("D3PM_SMALL_TARGET") ? atoi(getenv("D3PM_SMALL_TARGET")) : 512;   // (long rows: B = 8 x 32768 positions 24.1 -> 18.9 us against 1024)
+      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : small_target);
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }

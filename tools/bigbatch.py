@@ -1,7 +1,7 @@
 """Fused hybrid loss (K = 32) and LVB loss (n_tokens = 24) forward + backward over a range of batch sizes at L = 512,
 back-to-back launches between two HIP events: where the per-batch-element launch shape hands over to the chunked one.
 
-    python tools/bigbatch.py [--batches 256,320,384,512,1024,2048]
+    python tools/bigbatch.py [--batches 256,320,384,512,1024,2048] [--L 512] [--msa 0]
 """
 import argparse
 import os
@@ -19,11 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="256,320,384,512,1024,2048")
     ap.add_argument("--reps", type=int, default=100)
+    ap.add_argument("--L", type=int, default=512)
+    ap.add_argument("--msa", type=int, default=0, help="depth passed to d3pm_lvb_loss (0: single sequences)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     sp = stream_ptr()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    L, K, T, lam = 512, 32, 500, 0.001
+    L, K, T, lam = args.L, 32, 500, 0.001
     d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform",
                                    num_bits=5, transition_bands=None, model_prediction="x_start", model_output="logits",
                                    loss_type="hybrid", hybrid_coeff=lam, device=dev)
@@ -68,7 +70,7 @@ def main():
         wsbp = lib.d3pm_lvb_loss_workspace(B, L, 22)
         wsp = torch.empty(max(wsbp // 8, 1), dtype=torch.float64, device=dev)
         us_l = timed(lambda: check(lib.d3pm_lvb_loss(ptab.desc(), ptr(pr), 24, ptr(x0p), ptr(xtp), ptr(tp), None, B, L, 500,
-                                                     0, 1.0 / B, ptr(per), ptr(dp), ptr(wsp), wsbp, sp)))
+                                                     args.msa, 1.0 / B, ptr(per), ptr(dp), ptr(wsp), wsbp, sp)))
         n = B * L
         print(f"B={B:5d}  hybrid {us_h:7.2f} us  {272 * n / us_h / 8e6:5.3f} of HBM   lvb {us_l:7.2f} us  "
               f"{208 * n / us_l / 8e6:5.3f} of HBM", flush=True)
