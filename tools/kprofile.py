@@ -4,7 +4,7 @@ denoiser, a handful of torch launches for set-up only): the program that the roc
 run.  Prints each kernel's average duration between two HIP events, back to back on the launch stream, and its
 fraction of the 8 TB/s HBM roofline for the algorithmic bytes named in the table below.
 
-    python tools/kprofile.py [--reps 200] [--only hybrid,lvb,...]
+    python tools/kprofile.py [--reps 200] [--only hybrid,lvb,...] [--big]
 """
 import argparse
 import json
@@ -25,6 +25,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--only", default="")
+    ap.add_argument("--big", action="store_true",
+                    help="also time the two loss kernels at B = 2048 (left out of the profiled runs: the LVB launch would "
+                         "share a kernel name with the B = 256 one and mix the per-kernel averages)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     dev = torch.device("cuda", 0)
@@ -137,7 +140,7 @@ def main():
     # ---- the same two losses at eight times the batch (the global batch of 2048 on one GPU: 1 M tokens, 285 / 218 MB
     # per launch, more than the 256 MiB Infinity Cache holds): what the kernels reach once the launch overhead and
     # the arrival of the first rows are a small part of the launch
-    if not only or only & {"hybrid_b2048", "lvb_b2048"}:
+    if args.big or only & {"hybrid_b2048", "lvb_b2048"}:
         BB = 2048
         x0b = torch.randint(0, K, (BB, L, 1, 1), device=dev)
         lgb = torch.randn(BB, L, 1, 1, K, device=dev)
