@@ -262,7 +262,7 @@ def _oracle_process(betas, kind, K, lam):
 
 
 @pytest.mark.parametrize("K", [8, 16, 24, 32])
-@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (1, 64), (192, 1100), (300, 70), (600, 300), (450, 40)])
+@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (1, 64), (192, 1100), (300, 70), (600, 300), (450, 40), (257, 513)])
 def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
     """The fused loss kernels that give a lane a whole token (structured tables, K in {8, 16, 24, 32}, rows 16-byte
     aligned) or, for K = 32 with one workgroup per batch element (B >= 192), a pair of lanes: ragged last wave,

@@ -216,7 +216,7 @@ def test_lvb_loss_msa_against_oracle(pkg, tables500, n_tok, B, D, L):
     np.testing.assert_allclose(float(lvb.detach()), float(per_ref.detach().sum() / B), rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,L", [(1030, 270), (400, 263)])
+@pytest.mark.parametrize("B,L", [(1030, 270), (400, 263), (257, 513)])
 def test_lvb_loss_large_batch_against_oracle(pkg, tables500, B, L):
     """Batches beyond one workgroup per CU run the training kernel in 256-thread workgroups whose waves walk
     several passes (B = 1030: one chunk of two passes, the second ragged) or in chunks summed by a second launch
