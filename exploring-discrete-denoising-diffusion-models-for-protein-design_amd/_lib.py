@@ -65,6 +65,7 @@ SIGNATURES = {
     "d3pm_corrupt": (_I, [_T64, _P, _P, _I, _L, _P, _U64, _U64, _P, _P, _P]),
     "d3pm_lvb_loss_workspace": (_SZ, [_I, _L, _I]),
     "d3pm_lvb_loss": (_I, [_T64, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _D, _P, _P, _P, _SZ, _P]),
+    "d3pm_lvb_hybrid_loss": (_I, [_T64, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _D, _D, _P, _P, _P, _P, _SZ, _P]),
     "d3pm_lvb_reverse_step": (_I, [_T64, _P, _L, _P, _P, _I, _L, _P, _U64, _U64, _P, _D, _L, _P, _P]),
 }
 

@@ -195,11 +195,16 @@ __device__ __forceinline__ void marginal(const double (&p)[L::V], const double (
 }
 
 // ------------------------------------------------------------------ LVB loss
+// `hyb`: the driver's cross-entropy term as well (Protein Generation Notebook cell-12:
+// loss = (lvb + lambda * CrossEntropyLoss(outputs, tgt)) * n_tokens): per token -log_softmax(z)[x0] over ALL ld
+// logits, whatever the element's timestep, summed into part_ce; its gradient, weighted ce_scale / npos per token,
+// is added to the LVB gradient in the same store.
 template <class L, bool GRAD>
 __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __restrict__ pred, long ld,
                                                      const double* __restrict__ q, int tmax, int msa, double grad_scale,
                                                      double log_prior, double* __restrict__ part,
-                                                     float* __restrict__ dpred) {
+                                                     float* __restrict__ dpred, int hyb, double ce_scale,
+                                                     double* __restrict__ part_ce) {
   __shared__ double red[PBLOCK / 64];
   const int K = a.tb.K;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
     load_digest_d<L>(a.tb.qbar_digest, t - 1, 3, K, g, lmo);
   }
   const double cscale = grad_scale / (double)a.npos;
-  double acc = 0;
+  const double ces = hyb ? ce_scale / (double)a.npos : 0.0;
+  double acc = 0, acc_ce = 0;
   const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
   for (long pos = chunk * a.chunk_pos + slot; pos < p1; pos += PBLOCK / L::G) {
     const long n = (long)b * a.npos + pos;
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
 #pragma unroll
     for (int v = 0; v < L::V; ++v) gz[v] = 0.0f;
     double tok_loss = 0;
-    if (branch == 0) {
-      // CrossEntropyLoss over all ld logits (losses.py:54), float32
+    if (branch == 0 || hyb) {
+      // CrossEntropyLoss over all ld logits (losses.py:54 for t == 1; the driver's second loss term), float32
       load_slots<L>(pred + n * ld, g, (int)ld, -INFINITY, z);
       float m = -INFINITY;
 #pragma unroll
@@ -240,12 +246,17 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
       }
       s = group_sum<L::G>(s);
       zx0 = group_sum<L::G>(zx0);
-      tok_loss = (double)((m + logf(s)) - zx0);
+      const double ce_tok = (double)((m + logf(s)) - zx0);
+      if (branch == 0) tok_loss = ce_tok;
+      if (g == 0) acc_ce += ce_tok;
       if constexpr (GRAD) {
+        const double w = (branch == 0 ? cscale : 0.0) + ces;
 #pragma unroll
         for (int v = 0; v < L::V; ++v)
-          gz[v] = (float)(cscale * (double)(e[v] / s - ((L::cls(g, v) == x0) ? 1.0f : 0.0f)));
+          gz[v] = (float)(w * (double)(e[v] / s - ((L::cls(g, v) == x0) ? 1.0f : 0.0f)));
       }
+    }
+    if (branch == 0) {
     } else if (branch == 1) {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60)
       // (no probabilities given: the element's loss is NaN, nothing is read)
@@ -319,8 +330,9 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
           dot += p[v] * gp[v];
         }
         dot = group_sum<L::G>(dot);
+        // (gz holds the cross-entropy term's gradient, or zero)
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) gz[v] = (L::cls(g, v) < K) ? (float)(p[v] * (gp[v] - dot)) : 0.0f;
+        for (int v = 0; v < L::V; ++v) gz[v] += (L::cls(g, v) < K) ? (float)(p[v] * (gp[v] - dot)) : 0.0f;
       }
     }
     if constexpr (GRAD) store_slots<L>(dpred + n * ld, g, (int)ld, gz);
@@ -328,6 +340,10 @@ __global__ __launch_bounds__(PBLOCK) void k_lvb_loss(ProtArgs a, const float* __
   }
   const double s = block_sum(acc, red);
   if (threadIdx.x == 0) part[(size_t)b * a.chunks + chunk] = s;
+  if (hyb) {
+    const double sc = block_sum(acc_ce, red);
+    if (threadIdx.x == 0) part_ce[(size_t)b * a.chunks + chunk] = sc;
+  }
 }
 
 // ------------------------------------------------------------------ LVB loss, one token per lane, float32
@@ -362,15 +378,22 @@ __device__ __forceinline__ float log2_1p(float d) {
   return fmaf(d - (w - 1.0f), 1.44269504088896340736f, __builtin_amdgcn_logf(w));
 }
 
-template <int K, int LD, bool MSA>
+// HYB: the driver's cross-entropy term in the same pass (Protein Generation Notebook cell-12, loss = (lvb + lambda *
+// CrossEntropyLoss(outputs, tgt)) * n_tokens): -log_softmax(z)[x0] over ALL LD logits for every token whatever its
+// element's timestep, summed per sequence into ce_seq; its gradient ce_scale / npos * (softmax(z) - e_x0) rides in
+// the coefficients of the gradient's last loop (softmax_j = e_j f / S_all: one more term on e_j), so a class costs
+// no further operation.  The softmax of the KL branch runs over the first K logits with their own maximum; the
+// LD - K further logits enter through m_all = max(m, z_K..) and f = 2^(m - m_all), every exponent <= 0.
+template <int K, int LD, bool MSA, bool HYB>
 __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* __restrict__ pred,
                                                       const double* __restrict__ q, int tmax, int msa, float grad_scale,
-                                                      double log_prior, double* __restrict__ part,
-                                                      double* __restrict__ per_seq, float* __restrict__ dpred) {
+                                                      float ce_scale, double log_prior, double* __restrict__ part,
+                                                      double* __restrict__ per_seq, double* __restrict__ ce_seq,
+                                                      float* __restrict__ dpred) {
   using Img = RowImage<LD>;
   constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
   extern __shared__ __align__(16) char lvb_rows[];          // [waves][64][STRIDE]
-  __shared__ double red[8];
+  __shared__ double red[HYB ? 16 : 8];
   // per wave: a_diag, a_off (Q_t), mo, den diag / off (Qbar_t); MSA: rho diag / off, log rho diag / off
   __shared__ float s_tab[8][MSA ? 9 : 5][32];
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
@@ -427,14 +450,15 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     for (int j = 0; j < K; ++j) mo[j] = lane_broadcast(vo, j);
   }
   const float cs = grad_scale / (float)a.npos;
-  double acc = 0;
+  const float ces = HYB ? ce_scale / (float)a.npos : 0.0f;
+  double acc = 0, acc_ce = 0;
   for (;; base += blockDim.x) {
     if (base >= p1) break;                                   // (uniform over the wave)
     const bool live = base + lane < p1;
     x0 = clamp_index(x0, K);                                 // out-of-range tokens are clamped: nothing faults
     xt = clamp_index(xt, K);
     float e[LD];
-    float tok_loss = 0, add0 = 0, addt = 0;
+    float tok_loss = 0, tok_ce = 0, add0 = 0, addt = 0;
     if (branch == 1) {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
       if (live && !q) acc = (double)NAN;                       // no probabilities given: NaN, nothing is read
@@ -446,16 +470,20 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         // depth D for an MSA laid out [D,L,K]
         acc += s * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
       }
+      if constexpr (!HYB) {
 #pragma unroll
-      for (int j = 0; j < LD; ++j) e[j] = 0.0f;
-    } else {
+        for (int j = 0; j < LD; ++j) e[j] = 0.0f;
+      }
+    }
+    if (branch != 1 || HYB) {
       rows.deposit_flat(img, lane, ls);
       wave_lds_order();
       Img::read_row(img, lane, e);
       const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
       constexpr int KS = LD;                                 // classes of the softmax of this branch
-      if (branch == 0) {
-        // CrossEntropyLoss over all LD logits (losses.py:54)
+      if (branch != 2) {
+        // CrossEntropyLoss over all LD logits: the loss of an element at t == 1 (losses.py:54) and the driver's
+        // second term (every element)
         float m = e[0];
 #pragma unroll
         for (int j = 1; j < KS; ++j) m = fmaxf(m, e[j]);
@@ -463,11 +491,13 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         float s = 0;
 #pragma unroll
         for (int j = 0; j < KS; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
-        tok_loss = fmaf(__builtin_amdgcn_logf(s), LN2, m - z_x0);
-        const float wi = cs * __builtin_amdgcn_rcpf(s);
+        tok_ce = fmaf(__builtin_amdgcn_logf(s), LN2, m - z_x0);
+        tok_loss = branch == 0 ? tok_ce : 0.0f;                // (t == tmax: the element's term went to acc above)
+        const float w = (branch == 0 ? cs : 0.0f) + ces;
+        const float wi = w * __builtin_amdgcn_rcpf(s);
 #pragma unroll
         for (int j = 0; j < KS; ++j) e[j] *= wi;
-        add0 = -cs;
+        add0 = -w;
       } else {
         const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
         float m = e[0];
@@ -555,15 +585,39 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         const float W = fmaf(g0, sum_mo, fmaf(-g1, Hq, fmaf(d0, mo_x0, dt * mo_xt)));
         const float Sg = fmaf(inv2, fmaf(g0, E2, -g1 * Hp), fmaf(pp_x0, d0, pp_xt * dt));    // sum_i p_i^2 gs_i
         const float dot = 2.0f * fmaf(W, S2, mdo * Sg);
-        const float c4 = 2.0f * inv2 * fmaf(mdo, g0, W), c5 = 2.0f * inv2 * mdo * g1, c6 = inv * dot;
-#pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = fmaf(e2[j], fmaf(-c5, qv[j], c4), -c6 * e[j]);
-#pragma unroll
-        for (int j = K; j < LD; ++j) e[j] = 0.0f;
+        const float c4 = 2.0f * inv2 * fmaf(mdo, g0, W), c5 = 2.0f * inv2 * mdo * g1;
+        float c6 = inv * dot;
         add0 = 2.0f * pp_x0 * mdo * d0;
         addt = 2.0f * pp_xt * mdo * dt;
+        if constexpr (HYB) {
+          // softmax over all LD logits from the K exponentials at hand: softmax_j = e_j f / S_all
+          float S_all = s, f = 1.0f, m_all = m;
+          if constexpr (LD > K) {
+            float mx = e[K];
+#pragma unroll
+            for (int j = K + 1; j < LD; ++j) mx = fmaxf(mx, e[j]);
+            m_all = fmaxf(m, mx);
+            const float mneg_all = -m_all * LOG2E;
+            f = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, mneg_all));
+            S_all = s * f;
+#pragma unroll
+            for (int j = K; j < LD; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg_all)); S_all += e[j]; }
+          }
+          tok_ce = fmaf(__builtin_amdgcn_logf(S_all), LN2, m_all - z_x0);
+          const float wi = ces * __builtin_amdgcn_rcpf(S_all);
+          c6 = fmaf(-wi, f, c6);
+          add0 -= ces;
+#pragma unroll
+          for (int j = K; j < LD; ++j) e[j] *= wi;
+        } else {
+#pragma unroll
+          for (int j = K; j < LD; ++j) e[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) e[j] = fmaf(e2[j], fmaf(-c5, qv[j], c4), -c6 * e[j]);
       }
       acc += live ? (double)tok_loss : 0.0;
+      if constexpr (HYB) acc_ce += live ? (double)tok_ce : 0.0;
     }
     // gradient rows back through the image; the special classes are patched in the lane's own row
     Img::write_row(img, lane, e);
@@ -576,23 +630,41 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     issue(base + blockDim.x);
   }
   acc = wave_sum(acc);
-  if (lane == 0) red[wave] = acc;
+  if constexpr (HYB) acc_ce = wave_sum(acc_ce);
+  if (lane == 0) {
+    red[wave] = acc;
+    if constexpr (HYB) red[8 + wave] = acc_ce;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double sacc = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sacc += red[w];
+    double sacc = 0, sce = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      sacc += red[w];
+      if constexpr (HYB) sce += red[8 + w];
+    }
     if (a.chunks == 1) per_seq[b] = sacc / (double)a.npos;
     else part[(size_t)b * a.chunks + chunk] = sacc;
+    if constexpr (HYB) {
+      if (a.chunks == 1) { if (ce_seq) ce_seq[b] = sce / (double)a.npos; }
+      else part[(size_t)a.B * a.chunks + (size_t)b * a.chunks + chunk] = sce;
+    }
   }
 }
 
+// per_seq[b] = sum of the element's chunk partials / npos; the same for the cross-entropy partials (second half of
+// `part`) when ce_seq is given.
 __global__ void k_lvb_finalize(const double* __restrict__ part, int B, int chunks, long npos,
-                               double* __restrict__ per_seq) {
+                               double* __restrict__ per_seq, double* __restrict__ ce_seq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double s = 0;
   for (int c = 0; c < chunks; ++c) s += part[(size_t)b * chunks + c];
   per_seq[b] = s / (double)npos;
+  if (ce_seq) {
+    double sc = 0;
+    for (int c = 0; c < chunks; ++c) sc += part[(size_t)B * chunks + (size_t)b * chunks + c];
+    ce_seq[b] = sc / (double)npos;
+  }
 }
 
 // ------------------------------------------------------------------ reverse step
@@ -1052,13 +1124,14 @@ extern "C" size_t d3pm_lvb_loss_workspace(int B, long npos, int K) {
   (void)K;
   long passes = npos > 0 ? npos : 1;
   long chunks = passes < 4096 ? passes : 4096;
-  return (size_t)(B > 0 ? B : 1) * (size_t)chunks * sizeof(double);
+  // (two partial sums per workgroup: the element's loss term and its cross-entropy)
+  return 2 * (size_t)(B > 0 ? B : 1) * (size_t)chunks * sizeof(double);
 }
 
-extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
-                             const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax, int msa,
-                             double grad_scale, double* per_seq, float* dpred, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                         const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax, int msa,
+                         double grad_scale, bool hyb, double ce_grad_scale, double* per_seq, double* ce_seq,
+                         float* dpred, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_prot(tb, B, npos)) return rc;
   D3PM_CHECK_ARG(ld >= tb->K && ld <= 256, "row stride (n_tokens) must be in [K, 256], got %ld", ld);
   if (B == 0) return D3PM_OK;
@@ -1098,29 +1171,33 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
     }
     double* part = (double*)workspace;
     if (a.chunks > 1) {
-      const size_t need = (size_t)B * a.chunks * sizeof(double);
+      const size_t need = (hyb ? 2 : 1) * (size_t)B * a.chunks * sizeof(double);
       D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     }
-    auto go = [&](auto ldc, auto msac) -> int {
+    auto go = [&](auto ldc, auto msac, auto hybc) -> int {
       constexpr int LDC = decltype(ldc)::value;
-      auto kern = k_lvb_loss_tpl<22, LDC, decltype(msac)::value>;
+      auto kern = k_lvb_loss_tpl<22, LDC, decltype(msac)::value, decltype(hybc)::value>;
       const size_t sh = (size_t)(block / 64) * RowImage<LDC>::BYTES;
       if (sh > 48 * 1024) {
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       }
       hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, pred, q, tmax, msa, (float)grad_scale,
-                         log_prior, part, per_seq, dpred);
+                         (float)ce_grad_scale, log_prior, part, per_seq, ce_seq, dpred);
       D3PM_LAUNCH_CHECK("k_lvb_loss_tpl");
       return D3PM_OK;
     };
     using I22 = std::integral_constant<int, 22>;
     using I24 = std::integral_constant<int, 24>;
-    const int rc = msa > 0 ? (ld == 22 ? go(I22{}, std::true_type{}) : go(I24{}, std::true_type{}))
-                           : (ld == 22 ? go(I22{}, std::false_type{}) : go(I24{}, std::false_type{}));
+    auto go_h = [&](auto ldc, auto msac) -> int {
+      return hyb ? go(ldc, msac, std::true_type{}) : go(ldc, msac, std::false_type{});
+    };
+    const int rc = msa > 0 ? (ld == 22 ? go_h(I22{}, std::true_type{}) : go_h(I24{}, std::true_type{}))
+                           : (ld == 22 ? go_h(I22{}, std::false_type{}) : go_h(I24{}, std::false_type{}));
     if (rc) return rc;
     if (a.chunks > 1) {
-      hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);
+      hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq,
+                         hyb ? ce_seq : nullptr);
       D3PM_LAUNCH_CHECK("k_lvb_finalize");
     }
     return D3PM_OK;
@@ -1128,22 +1205,41 @@ extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long 
   auto run = [&](auto lay) {
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, L::G);
-    const size_t need = (size_t)B * a.chunks * sizeof(double);
+    const size_t need = (hyb ? 2 : 1) * (size_t)B * a.chunks * sizeof(double);
     D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     double* part = (double*)workspace;
+    double* part_ce = part + (size_t)B * a.chunks;
     const dim3 grid(B * a.chunks), block(PBLOCK);
     if (dpred)
       hipLaunchKernelGGL((k_lvb_loss<L, true>), grid, block, 0, s, a, pred, ld, q, tmax, msa, grad_scale, log_prior,
-                         part, dpred);
+                         part, dpred, hyb ? 1 : 0, ce_grad_scale, part_ce);
     else
       hipLaunchKernelGGL((k_lvb_loss<L, false>), grid, block, 0, s, a, pred, ld, q, tmax, msa, grad_scale, log_prior,
-                         part, dpred);
+                         part, dpred, hyb ? 1 : 0, ce_grad_scale, part_ce);
     D3PM_LAUNCH_CHECK("k_lvb_loss");
-    hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq);
+    hipLaunchKernelGGL(k_lvb_finalize, dim3((B + 255) / 256), dim3(256), 0, s, part, B, a.chunks, npos, per_seq,
+                       hyb ? ce_seq : nullptr);
     D3PM_LAUNCH_CHECK("k_lvb_finalize");
     return D3PM_OK;
   };
   return dispatch_layout((int)ld, false, run);       // (four lanes per token measured no faster than eight)
+}
+
+extern "C" int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                             const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax, int msa,
+                             double grad_scale, double* per_seq, float* dpred, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  return lvb_loss_impl(tb, pred, ld, x0, x_t, t, q, B, npos, tmax, msa, grad_scale, false, 0.0, per_seq, nullptr, dpred,
+                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int d3pm_lvb_hybrid_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                                    const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax,
+                                    int msa, double grad_scale, double ce_grad_scale, double* per_seq, double* ce_seq,
+                                    float* dpred, void* workspace, size_t workspace_bytes, void* stream) {
+  D3PM_CHECK_ARG(ce_seq, "null pointer (ce_seq)");
+  return lvb_loss_impl(tb, pred, ld, x0, x_t, t, q, B, npos, tmax, msa, grad_scale, true, ce_grad_scale, per_seq, ce_seq,
+                       dpred, workspace, workspace_bytes, stream);
 }
 
 extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x_t,

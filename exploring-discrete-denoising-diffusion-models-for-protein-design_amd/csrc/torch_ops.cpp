@@ -206,6 +206,28 @@ std::tuple<Tensor, Tensor> lvb_loss(const Tensor& qbar_digest, const Tensor& qon
   return {per, dp};
 }
 
+// the same with the driver's cross-entropy term (Protein Generation Notebook cell-12: (lvb + lambda ce) n_tokens):
+// returns (per_seq, ce_seq, dpred)
+std::tuple<Tensor, Tensor, Tensor> lvb_hybrid_loss(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T,
+                                                   const Tensor& pred, const Tensor& x0, const Tensor& x_t, const Tensor& t,
+                                                   const OptTensor& q, int64_t tmax, int64_t msa, double grad_scale,
+                                                   double ce_grad_scale, bool want_grad) {
+  auto tb = protein_tables(qbar_digest, qone_digest, K, T);
+  auto [B, npos] = dims(x0);
+  TORCH_CHECK(tok_bytes(x0, "x0") == 8 && tok_bytes(x_t, "x_t") == 8 && tok_bytes(t, "t") == 8,
+              "d3pm_mi355x: protein-style tokens and timesteps are int64");
+  auto dopt = pred.options().dtype(at::kDouble);
+  Tensor per = at::empty({B}, dopt), ce = at::empty({B}, dopt);
+  Tensor dp = want_grad ? at::empty_like(pred) : at::empty({0}, pred.options());
+  const size_t wsb = d3pm_lvb_loss_workspace(B, npos, (int)K);
+  Tensor ws = at::empty({(int64_t)(wsb / 8 + 1)}, dopt);
+  check_rc(d3pm_lvb_hybrid_loss(&tb, f32(pred, "pred"), pred.size(-1), x0.data_ptr<int64_t>(), x_t.data_ptr<int64_t>(),
+                                t.data_ptr<int64_t>(), (const double*)opt_ptr(q, at::kDouble, "q"), B, npos, (int)tmax,
+                                (int)msa, grad_scale, ce_grad_scale, per.data_ptr<double>(), ce.data_ptr<double>(),
+                                want_grad ? dp.data_ptr<float>() : nullptr, ws.data_ptr(), wsb, stream()));
+  return {per, ce, dp};
+}
+
 // reverse step of generate_d3pm / generate_msa_d3pm, protein_generation/generate.py:28-40, :70-93
 Tensor lvb_reverse_step(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T, const Tensor& pred,
                         const Tensor& x_t, const Tensor& t, const OptTensor& expo, int64_t seed, int64_t offset,
@@ -256,6 +278,8 @@ TORCH_LIBRARY(d3pm_mi355x, m) {
   m.def("prior_bpd(" D3PM_TB "Tensor x0, bool absorbing) -> Tensor");
   m.def("lvb_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
         "float grad_scale, bool want_grad) -> (Tensor, Tensor)");
+  m.def("lvb_hybrid_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
+        "float grad_scale, float ce_grad_scale, bool want_grad) -> (Tensor, Tensor, Tensor)");
   m.def("lvb_reverse_step(" D3PM_PT "Tensor pred, Tensor x_t, Tensor t, Tensor? expo, int seed, int offset, "
         "Tensor? offset_dev, float last_class_div, int exclude_last_prefix) -> Tensor");
   m.def("corrupt(" D3PM_PT "Tensor x0, Tensor t, Tensor? expo, int seed, int offset, bool want_probs) -> (Tensor, Tensor)");
@@ -271,6 +295,7 @@ TORCH_LIBRARY_IMPL(d3pm_mi355x, CUDA, m) {
   m.impl("p_sample", p_sample);
   m.impl("prior_bpd", prior_bpd);
   m.impl("lvb_loss", lvb_loss);
+  m.impl("lvb_hybrid_loss", lvb_hybrid_loss);
   m.impl("lvb_reverse_step", lvb_reverse_step);
   m.impl("corrupt", corrupt);
 }

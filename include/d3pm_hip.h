@@ -312,6 +312,22 @@ int d3pm_lvb_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const i
                   int msa, double grad_scale, double* per_seq, float* dpred,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The protein-style training loss as the driver forms it (Protein Generation
+ * Notebook.ipynb cell-12 / cell-13):
+ *   loss = (lvb + lambda * CrossEntropyLoss(outputs.reshape(-1, n), tgt.reshape(-1))) * n_tokens
+ * d3pm_lvb_loss plus, in the same pass over the same rows, the cross-entropy of
+ * EVERY token whatever its element's timestep: -log_softmax(pred)[x0] over all
+ * ld logits (losses.py:52-55 is the same term for an element at t == 1).
+ *   ce_seq float64 [B]: mean over the element's positions of that term, so that
+ *     the driver's batch mean is sum_b ce_seq[b] / B
+ *   dpred: gradient of grad_scale * sum_b per_seq[b] + ce_grad_scale * sum_b ce_seq[b];
+ *     the notebook's loss is grad_scale = n_tokens / B, ce_grad_scale = lambda * n_tokens / B
+ * Everything else as d3pm_lvb_loss (whose workspace size serves both). */
+int d3pm_lvb_hybrid_loss(const d3pm_tables_f64* tb, const float* pred, long ld, const int64_t* x0,
+                         const int64_t* x_t, const int64_t* t, const double* q, int B, long npos, int tmax,
+                         int msa, double grad_scale, double ce_grad_scale, double* per_seq, double* ce_seq,
+                         float* dpred, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Reverse step of generate_d3pm (generate.py:28-40) and of generate_msa_d3pm
  * (generate.py:70-93): x_{t-1} = argmax_j(P_j / E_j), P the normalised p-squared
  * marginal; expo float64 [B,npos,K] holds the Exp(1) draws E, or is NULL for

@@ -128,6 +128,20 @@ def lvb(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, **kw) -
     return per.sum() / tgt.shape[0]
 
 
+def driver_loss(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, lam: float, **kw):
+    """Protein Generation Notebook.ipynb cell-12 / cell-13, the loss the training loop differentiates:
+    ``(lvb + lam * ce) * n_tokens`` with ``ce = CrossEntropyLoss(mean)(outputs.reshape(-1, n), tgt.reshape(-1))``,
+    both terms cast to float32 and ``n_tokens = src.shape[0] * src.shape[1]`` (B*L for sequences, B*D for MSAs).
+    Returns (loss, lvb, ce)."""
+    lvb_loss = lvb(src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q, Q_bar, **kw)
+    ce_loss = torch.nn.CrossEntropyLoss(weight=None, reduction="mean")(
+        predictions.reshape(-1, predictions.shape[-1]), tgt.reshape(-1))
+    n_tokens = tgt.shape[0] * tgt.shape[1]
+    lvb_loss = lvb_loss.to(torch.float32)
+    ce_loss = ce_loss.to(torch.float32)
+    return (lvb_loss + (lam * ce_loss)) * n_tokens, lvb_loss, ce_loss
+
+
 def reverse_marginal(logits: torch.Tensor, x_t: torch.Tensor, Qt: torch.Tensor, Qm: torch.Tensor,
                      K: int = K_MSA) -> torch.Tensor:
     """generate.py:28-39 for one sequence: normalised p_theta(x_{t-1}|x_t)

@@ -216,6 +216,100 @@ def test_lvb_loss_msa_against_oracle(pkg, tables500, n_tok, B, D, L):
     np.testing.assert_allclose(float(lvb.detach()), float(per_ref.detach().sum() / B), rtol=1e-5)
 
 
+@pytest.mark.parametrize("n_tok", [22, 24])
+@pytest.mark.parametrize("lam", [0.001, 0.5])
+def test_driver_loss_golden(pkg, tables500, n_tok, lam):
+    """The training loop's loss, (lvb + lambda * ce) * n_tokens (notebook cell-12), from the module with
+    hybrid_coeff / out_scale: value, cross-entropy term and gradient against the reference's, one launch."""
+    tok, Qb, Qt = tables500
+    g, h = golden("protein_lvb_blat"), golden("protein_driver_loss")
+    x0, x_t, ts, q = T_(g["x0"]), T_(g["x_t"]), T_(g["timestep"]), T_(g["q"])
+    pred = T_(g[f"pred{n_tok}"]).requires_grad_(True)
+    n_tokens = x0.shape[0] * x0.shape[1]
+    lf = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, hybrid_coeff=lam)
+    loss = lf(None, q, pred, x0, None, ts, Qt, Qb, src=x_t, out_scale=n_tokens)
+    np.testing.assert_allclose(float(loss.detach()), h[f"loss{n_tok}_lam{lam}"], rtol=1e-5)
+    np.testing.assert_allclose(float(lf.ce_loss), g[f"ce{n_tok}"], rtol=1e-5)
+    loss.backward()
+    ref = h[f"grad{n_tok}_lam{lam}"]
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+    # the notebook's own spelling: the module's value times n_tokens outside (upstream gradient != baked scale)
+    pred2 = T_(g[f"pred{n_tok}"]).requires_grad_(True)
+    lf2 = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, hybrid_coeff=lam)
+    (lf2(tok.one_hot(x_t), q, pred2, x0, tok.one_hot(x0), ts, Qt, Qb) * n_tokens).backward()
+    np.testing.assert_allclose(pred2.grad.cpu().numpy(), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+    # forward-only evaluation (float64 kernel) carries the term too: per-sequence lvb + lambda * ce
+    with torch.no_grad():
+        lf3 = pkg.D3PMLVBLoss(tmax=500, tokenizer=tok, evaluation=True, hybrid_coeff=lam)
+        per = lf3(None, q, pred, x0, None, ts, Qt, Qb, src=x_t)
+    want = g[f"per_seq{n_tok}"] + lam * lf3.ce_seq.cpu().numpy()
+    np.testing.assert_allclose(per.cpu().numpy(), want, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(float(lf3.ce_loss), g[f"ce{n_tok}"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("lam", [0.001, 0.5])
+def test_driver_loss_msa_golden(pkg, tables500, lam):
+    """Notebook cell-13: the same loop around D3PMLVBLossMSA, n_tokens = B * D."""
+    tok, Qb, Qt = tables500
+    g, h = golden("protein_lvb_msa"), golden("protein_driver_loss")
+    x0, x_t, ts, q = T_(g["x0"]), T_(g["x_t"]), T_(g["timestep"]), T_(g["q"])
+    pred = T_(g["pred"]).requires_grad_(True)
+    n_tokens = x0.shape[0] * x0.shape[1]
+    lf = pkg.D3PMLVBLossMSA(tmax=500, tokenizer=tok, hybrid_coeff=lam)
+    loss = lf(tok.one_hot(x_t), q, pred, x0, tok.one_hot(x0), ts, Qt, Qb, out_scale=n_tokens)
+    np.testing.assert_allclose(float(loss.detach()), h[f"msa_loss_lam{lam}"], rtol=1e-5)
+    np.testing.assert_allclose(float(lf.ce_loss), h["msa_ce"], rtol=1e-5)
+    loss.backward()
+    ref = h[f"msa_grad_lam{lam}"]
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,L,n_tok,msa", [(1030, 270, 24, 0), (400, 263, 22, 0), (256, 512, 24, 0), (200, 37 * 2, 24, 2),
+                                           (9, 300, 23, 0)])
+def test_driver_loss_against_oracle(pkg, tables500, B, L, n_tok, msa):
+    """d3pm_lvb_hybrid_loss at the launch shapes of the training kernel (one workgroup per element, 256-thread
+    workgroups walking several passes, chunks summed by a second launch, the MSA variant) and on the float64 kernel
+    (23 logits): per-sequence LVB, per-sequence cross-entropy and the gradient of
+    grad_scale * sum per_seq + ce_grad_scale * sum ce_seq against the CPU oracle, every timestep branch present.
+    Logits beyond the K classes are made large in some rows: the cross-entropy runs over all of them."""
+    from d3pm_amd._ops import ops
+    from d3pm_amd.tables import protein_tables
+    tok, Qb, Qt = tables500
+    gen = torch.Generator().manual_seed(B + n_tok)
+    x0 = torch.randint(0, 22, (B, L), generator=gen)
+    ts = torch.randint(1, 501, (B,), generator=gen)
+    ts[:4] = torch.tensor([1, 2, 500, 499])
+    Qb_c, Qt_c = Qb.cpu(), Qt.cpu()
+    probs = Qb_c[(ts - 1).clamp(max=499)][torch.arange(B)[:, None], x0]                   # [B, L, K]
+    x_t = torch.multinomial(probs.reshape(-1, 22), 1, generator=gen).reshape(B, L)
+    q = torch.softmax(torch.randn(B, L, 22, generator=gen, dtype=torch.float64), -1)
+    pred = torch.randn(B, L, n_tok, generator=gen) * 2.0
+    if n_tok > 22:
+        pred[::3, ::5, 22:] += 9.0                     # further logits above every class logit
+        pred[1::3, 1::5, 22:] -= 30.0
+    shape = (B, msa, L // msa) if msa else (B, L)
+    rs = lambda a: a.reshape(shape + a.shape[2:])
+    pr_ref = pred.clone().requires_grad_(True)
+    per_ref = pr.lvb_per_sequence(pr.one_hot(rs(x_t), 22), rs(q), rs(pr_ref), rs(x0), pr.one_hot(rs(x0), 22), ts,
+                                  Qt_c, Qb_c, K=22, tmax=500, msa=bool(msa))
+    ce_tok = torch.nn.functional.cross_entropy(pr_ref.reshape(-1, n_tok), x0.reshape(-1), reduction="none")
+    ce_ref = ce_tok.reshape(B, L).double().mean(dim=1)
+    gs, cgs = float(np.float32(3.0) / np.float32(B)), float(np.float32(0.7) / np.float32(B))
+    (per_ref.sum() * gs + ce_ref.sum() * cgs).backward()
+    tb = protein_tables(Qt, Qb)
+    per, ce, dp = ops.lvb_hybrid_loss(*tb.op_args(), pred.to(DEV), x0.to(DEV), x_t.to(DEV), ts.to(DEV), q.to(DEV), 500,
+                                      msa, gs, cgs, True)
+    np.testing.assert_allclose(per.cpu().numpy(), per_ref.detach().numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(ce.cpu().numpy(), ce_ref.detach().numpy(), rtol=1e-5)
+    ref = pr_ref.grad.numpy()
+    np.testing.assert_allclose(dp.cpu().numpy(), ref, rtol=1e-5, atol=GRAD_FLOOR * np.abs(ref).max())
+    # forward only (float64 kernel): the same two sums
+    per2, ce2, _ = ops.lvb_hybrid_loss(*tb.op_args(), pred.to(DEV), x0.to(DEV), x_t.to(DEV), ts.to(DEV), q.to(DEV),
+                                       500, msa, gs, cgs, False)
+    np.testing.assert_allclose(per2.cpu().numpy(), per_ref.detach().numpy(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(ce2.cpu().numpy(), ce_ref.detach().numpy(), rtol=1e-6)
+
+
 @pytest.mark.parametrize("B,L", [(1030, 270), (400, 263), (257, 513)])
 def test_lvb_loss_large_batch_against_oracle(pkg, tables500, B, L):
     """Batches beyond one workgroup per CU run the training kernel in 256-thread workgroups whose waves walk

@@ -162,6 +162,32 @@ def test_protein_lvb_msa():
     np.testing.assert_array_equal(gr.numpy(), g["grad"])
 
 
+def test_protein_driver_loss():
+    """(lvb + lambda * ce) * n_tokens of the training loop (notebook cell-12 / cell-13): value, gradient and the
+    cross-entropy term itself, single sequences (22 and 24 logits) and MSAs."""
+    g, h = golden("protein_lvb_blat"), golden("protein_driver_loss")
+    qb, qt = pr.uniform_tables(22, 500, "sohl-dickstein")
+    x0, x_t, ts = T_(g["x0"]), T_(g["x_t"]), T_(g["timestep"])
+    for n_tok in (22, 24):
+        for lam in (0.001, 0.5):
+            pred = T_(g[f"pred{n_tok}"]).requires_grad_(True)
+            loss, _, ce = pr.driver_loss(pr.one_hot(x_t), T_(g["q"]), pred, x0, pr.one_hot(x0), ts, qt, qb, lam)
+            np.testing.assert_array_equal(loss.detach().numpy(), h[f"loss{n_tok}_lam{lam}"])
+            np.testing.assert_array_equal(ce.detach().numpy(), g[f"ce{n_tok}"])
+            (gr,) = torch.autograd.grad(loss, pred)
+            np.testing.assert_array_equal(gr.numpy(), h[f"grad{n_tok}_lam{lam}"])
+    m = golden("protein_lvb_msa")
+    x0, x_t = T_(m["x0"]), T_(m["x_t"])
+    for lam in (0.001, 0.5):
+        pred = T_(m["pred"]).requires_grad_(True)
+        loss, _, ce = pr.driver_loss(pr.one_hot(x_t), T_(m["q"]), pred, x0, pr.one_hot(x0), T_(m["timestep"]), qt, qb,
+                                     lam, msa=True)
+        np.testing.assert_array_equal(loss.detach().numpy(), h[f"msa_loss_lam{lam}"])
+        np.testing.assert_array_equal(ce.detach().numpy(), h["msa_ce"])
+        (gr,) = torch.autograd.grad(loss, pred)
+        np.testing.assert_array_equal(gr.numpy(), h[f"msa_grad_lam{lam}"])
+
+
 def test_protein_generate_replay():
     g = golden("protein_generate")
     emb, tvec = T_(g["emb"]), T_(g["tvec"])

@@ -40,7 +40,12 @@ def fasta_tokens(n: int) -> np.ndarray:
     return np.array([[lut[c] for c in s] for s in seqs], dtype=np.int64)
 
 
+ONLY = None          # --only: names of the fixtures to (re)write; the others are computed and left as they are
+
+
 def save(name: str, **arrs):
+    if ONLY is not None and name not in ONLY:
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
@@ -291,6 +296,20 @@ def part_protein():
                      f"lvb{n_tok}": lvb.detach().numpy(), f"grad{n_tok}": gr.numpy(), f"ce{n_tok}": ce.detach().numpy()})
     save("protein_lvb_blat", **arrs)
 
+    # --- the training loop's loss around the module (Protein Generation Notebook cell-12) --------------
+    # loss = (lvb + _lambda * ce) * n_tokens, both terms cast to float32; inputs are those of protein_lvb_blat
+    hyb = {}
+    for n_tok in (22, 24):
+        for lam in (0.001, 0.5):
+            pred = torch.tensor(arrs[f"pred{n_tok}"]).requires_grad_(True)
+            lf = pl.D3PMLVBLoss(tmax=500, tokenizer=tok)
+            lvb_loss = lf(src_oh, q_x, pred, toks, tgt_oh, timestep, Qt, Qb)
+            ce_loss = torch.nn.CrossEntropyLoss(weight=None, reduction="mean")(pred.reshape(-1, pred.shape[-1]), toks.reshape(-1))
+            n_tokens = x_t.shape[0] * x_t.shape[1]
+            loss = (lvb_loss.to(torch.float32) + (lam * ce_loss.to(torch.float32))) * n_tokens
+            (gr,) = torch.autograd.grad(loss, pred)
+            hyb.update({f"loss{n_tok}_lam{lam}": loss.detach().numpy(), f"grad{n_tok}_lam{lam}": gr.numpy()})
+
     # --- LVB loss, MSA variant -----------------------------------------------------------
     g = torch.Generator().manual_seed(300)
     Bm, D, Lm = 4, 3, 40
@@ -309,6 +328,17 @@ def part_protein():
     (grm,) = torch.autograd.grad(lvbm, predm)
     save("protein_lvb_msa", x0=x0m.numpy(), x_t=xtm.numpy(), q=qm.numpy(), timestep=tm.numpy(),
          pred=predm.detach().numpy(), lvb=lvbm.detach().numpy(), grad=grm.numpy())
+    # cell-13: the same loop around the MSA module (n_tokens = src.shape[0] * src.shape[1] = B * D there)
+    for lam in (0.001, 0.5):
+        pm = predm.detach().clone().requires_grad_(True)
+        lvb_loss = lfm(tok.one_hot(xtm), qm, pm, x0m, tok.one_hot(x0m), tm, Qt, Qb)
+        ce_loss = torch.nn.CrossEntropyLoss(weight=None, reduction="mean")(pm.reshape(-1, pm.shape[-1]), x0m.reshape(-1))
+        n_tokens = xtm.shape[0] * xtm.shape[1]
+        loss = (lvb_loss.to(torch.float32) + (lam * ce_loss.to(torch.float32))) * n_tokens
+        (gr,) = torch.autograd.grad(loss, pm)
+        hyb.update({f"msa_loss_lam{lam}": loss.detach().numpy(), f"msa_grad_lam{lam}": gr.numpy(),
+                    "msa_ce": ce_loss.detach().numpy()})
+    save("protein_driver_loss", **hyb)
 
     # --- full reverse sampling run with a toy denoiser, draws replayed -------------------
     T, Bg, Lg = 20, 3, 48
@@ -431,14 +461,18 @@ def part_protein():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--part", choices=["image", "protein"], default=None)
+    ap.add_argument("--only", default=None, help="comma-separated fixture names to write (default: all)")
     a = ap.parse_args()
+    global ONLY
+    ONLY = set(a.only.split(",")) if a.only else None
     if a.part == "image":
         part_image()
     elif a.part == "protein":
         part_protein()
     else:
         for part in ("image", "protein"):
-            subprocess.run([sys.executable, "-B", os.path.abspath(__file__), "--part", part], check=True)
+            subprocess.run([sys.executable, "-B", os.path.abspath(__file__), "--part", part] +
+                           (["--only", a.only] if a.only else []), check=True)
 
 
 if __name__ == "__main__":
