@@ -179,12 +179,13 @@ def cpu_baselines(budget_s: float = 10.0):
 
     def lvb_step():
         pred.grad = None
-        pr.lvb(src_oh, None, pred, tg, tg_oh, tsp, qt, qb, K=K_PROT, tmax=T_PROT).backward()
+        pr.driver_loss(src_oh, None, pred, tg, tg_oh, tsp, qt, qb, LAMBDA, K=K_PROT, tmax=T_PROT)[0].backward()
 
     med_l, n_l = _median_time(lvb_step, budget_s)
     lvb = {"value": BS * LP / med_l, "unit": "tokens/s", "cores": cores, "kind": "port",
-           "sample": f"{n_l} steps of D3PMLVBLoss forward + backward on a {BS}-sequence slice (L={LP}, K={K_PROT}, "
-                     f"n_tokens={LDP}, 2 <= t < {T_PROT}), median {med_l * 1e3:.1f} ms per step; {host}"}
+           "sample": f"{n_l} steps of (D3PMLVBLoss + {LAMBDA} * CrossEntropyLoss) * n_tokens forward + backward (the "
+                     f"training loop's loss) on a {BS}-sequence slice (L={LP}, K={K_PROT}, n_tokens={LDP}, "
+                     f"2 <= t < {T_PROT}), median {med_l * 1e3:.1f} ms per step; {host}"}
 
     # reverse sampling: one step of generate_d3pm on a 256-sequence slice, extrapolated to the 499 steps
     BR = 256
@@ -258,6 +259,104 @@ def worker(args):
         return d
 
     d = process(args.kind)
+
+    def event_ms(fn, n, warm=10):
+        """Average duration of fn's launches back to back on the launch stream, between two HIP events."""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        until = time.perf_counter() + 0.1            # sustained clocks before anything is timed
+        while time.perf_counter() < until:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    def event_ms_replayed(fn_on, n, per_graph=50):
+        """The same figure with the host out of the way: `per_graph` launches of fn_on(stream pointer) captured back to
+        back into a HIP graph, replays timed between two HIP events on the replay stream (a Python call per launch
+        takes about as long as these kernels run, so eager back-to-back timing sits at the edge of being host-bound)."""
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn_on(stream_ptr())
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            spc = stream_ptr()
+            for _ in range(per_graph):
+                fn_on(spc)
+        reps = max(2, -(-n // per_graph))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * per_graph)
+
+    # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
+    # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
+    def fused_kernel_ms(dd, nsets=1, with_next=False, replayed=False):
+        """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
+        launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
+        tb = dd.tables()
+        t_s = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
+        sets = []
+        for i in range(nsets):
+            x0_i = x0 if i == 0 else torch.randint(0, K, (B, L, 1, 1), device=dev)
+            lg_i = logits.detach() if i == 0 else torch.randn(B, L, 1, 1, K, device=dev)
+            sets.append((x0_i, dd.q_sample(x0_i, t_s), lg_i, torch.empty_like(lg_i)))
+        loss_s = torch.empty(B, device=dev)
+        wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+        ws = torch.empty(max(wsb // 4, 1), device=dev)
+        state = {"i": 0}
+
+        def fused_only(spx=None):
+            x0_i, xt_i, lg_i, dl_i = sets[state["i"] % nsets]
+            state["i"] += 1
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
+                                       LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
+                                       None, 0, ptr(ws), wsb, sp if spx is None else spx))
+        if replayed:
+            return event_ms_replayed(fused_only, max(args.steps, 200), per_graph=10 * nsets if nsets > 1 else 50)
+        if not with_next:
+            # median of five blocks of back-to-back launches (a block that another tenant of the box disturbs does
+            # not decide the figure)
+            blocks = sorted(event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10) for _ in range(5))
+            return blocks[2]
+        t_n = torch.empty(B, dtype=torch.int32, device=dev)
+        xt_n = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
+
+        def fused_with_next():
+            x0_i, xt_i, lg_i, dl_i = sets[0]
+            check(lib.d3pm_hybrid_loss_then_q_sample(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
+                                                     LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s),
+                                                     ptr(dl_i), ptr(ws), wsb, ptr(x0_i), 8, 7, 0, None, ptr(t_n),
+                                                     ptr(xt_n), sp))
+        return event_ms(fused_with_next, max(args.steps, 200), warm=12)
+
+
+    if args.roofline_only:
+        # exactly the launch sequence roofline.frac is quoted on, and nothing else of this kernel: the program of the
+        # rocprofv3 kernel trace kept under profiles/ (its average duration of k_hybrid_loss_pair32<true, false> is
+        # this figure as the tracer sees it)
+        ms = fused_kernel_ms(d, nsets=10)
+        ach = BYTES_PER_TOKEN * B * L / (ms * 1e-3) / 1e9
+        print(json.dumps({"roofline_only": True, "kernel": "k_hybrid_loss_pair32<true, false>", "kernel_ms": ms,
+                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                          "launches": "10 rotating buffer sets, back to back between two HIP events, median of 5 blocks"}),
+              flush=True)
+        return
 
     # Default: DiscreteDiffusion.training_step -- timestep draw + q_sample (one launch, device Philox), fused loss
     # per example and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
@@ -431,94 +530,9 @@ def worker(args):
         torch.cuda.synchronize()
         other_ms = (time.perf_counter() - o0) * 10.0
 
-    def event_ms(fn, n, warm=10):
-        """Average duration of fn's launches back to back on the launch stream, between two HIP events."""
-        for _ in range(warm):
-            fn()
-        torch.cuda.synchronize()
-        until = time.perf_counter() + 0.1            # sustained clocks before anything is timed
-        while time.perf_counter() < until:
-            for _ in range(20):
-                fn()
-            torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-
-    def event_ms_replayed(fn_on, n, per_graph=50):
-        """The same figure with the host out of the way: `per_graph` launches of fn_on(stream pointer) captured back to
-        back into a HIP graph, replays timed between two HIP events on the replay stream (a Python call per launch
-        takes about as long as these kernels run, so eager back-to-back timing sits at the edge of being host-bound)."""
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn_on(stream_ptr())
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            spc = stream_ptr()
-            for _ in range(per_graph):
-                fn_on(spc)
-        reps = max(2, -(-n // per_graph))
-        for _ in range(3):
-            g.replay()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / (reps * per_graph)
-
-    # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
-    # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
-    def fused_kernel_ms(dd, nsets=1, with_next=False, replayed=False):
-        """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
-        launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
-        tb = dd.tables()
-        t_s = torch.randint(0, T, (B,), dtype=torch.int32, device=dev)
-        sets = []
-        for i in range(nsets):
-            x0_i = x0 if i == 0 else torch.randint(0, K, (B, L, 1, 1), device=dev)
-            lg_i = logits.detach() if i == 0 else torch.randn(B, L, 1, 1, K, device=dev)
-            sets.append((x0_i, dd.q_sample(x0_i, t_s), lg_i, torch.empty_like(lg_i)))
-        loss_s = torch.empty(B, device=dev)
-        wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
-        ws = torch.empty(max(wsb // 4, 1), device=dev)
-        state = {"i": 0}
-
-        def fused_only(spx=None):
-            x0_i, xt_i, lg_i, dl_i = sets[state["i"] % nsets]
-            state["i"] += 1
-            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
-                                       LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
-                                       None, 0, ptr(ws), wsb, sp if spx is None else spx))
-        if replayed:
-            return event_ms_replayed(fused_only, max(args.steps, 200), per_graph=10 * nsets if nsets > 1 else 50)
-        if not with_next:
-            # median of five blocks of back-to-back launches (a block that another tenant of the box disturbs does
-            # not decide the figure)
-            blocks = sorted(event_ms(fused_only, max(args.steps, 200), warm=2 * nsets + 10) for _ in range(5))
-            return blocks[2]
-        t_n = torch.empty(B, dtype=torch.int32, device=dev)
-        xt_n = torch.empty(B, L, 1, 1, dtype=torch.int64, device=dev)
-
-        def fused_with_next():
-            x0_i, xt_i, lg_i, dl_i = sets[0]
-            check(lib.d3pm_hybrid_loss_then_q_sample(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
-                                                     LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s),
-                                                     ptr(dl_i), ptr(ws), wsb, ptr(x0_i), 8, 7, 0, None, ptr(t_n),
-                                                     ptr(xt_n), sp))
-        return event_ms(fused_with_next, max(args.steps, 200), warm=12)
-
     progress("fused kernel back to back")
     kern_ms = fused_kernel_ms(d)
-    kern_rot_ms = None if args.no_secondary else fused_kernel_ms(d, nsets=10)
+    kern_rot_ms = fused_kernel_ms(d, nsets=10)
     kern_next_ms = fused_kernel_ms(d, with_next=True) if pipelined else None
     kern_replayed_ms = fused_kernel_ms(d, replayed=True) if not args.no_graph and not use_pg else None
 
@@ -652,6 +666,7 @@ def worker(args):
         predp = torch.randn(BP, LP, LDP, device=dev)
         dpp = torch.empty_like(predp)
         perp = torch.empty(BP, dtype=torch.float64, device=dev)
+        cep = torch.empty(BP, dtype=torch.float64, device=dev)
         wsbp = lib.d3pm_lvb_loss_workspace(BP, LP, KP)
         wsp = torch.empty(max(wsbp // 8, 1), dtype=torch.float64, device=dev)
 
@@ -659,6 +674,11 @@ def worker(args):
             check(lib.d3pm_corrupt(ptab.desc(), ptr(x0p), ptr(tp), BP, LP, None, 1, 0, ptr(xtp), None, sp))
 
         def lvb_loss():
+            # the training loop's loss (notebook cell-12): (lvb + lambda * ce) * n_tokens, n_tokens = B * L
+            check(lib.d3pm_lvb_hybrid_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
+                                           float(LP), LAMBDA * LP, ptr(perp), ptr(cep), ptr(dpp), ptr(wsp), wsbp, sp))
+
+        def lvb_only():
             check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
                                     1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
 
@@ -667,15 +687,18 @@ def worker(args):
             lvb_loss()
         lms = event_ms(lvb_step, 200, warm=20)
         lk_ms = event_ms(lvb_loss, 200)
+        lo_ms = event_ms(lvb_only, 200)
         lbytes = 8 * LDP + 16
         l_ach = lbytes * BP * LP / (lk_ms * 1e-3) / 1e9
-        lvb = {"workload": "protein-style step: batched forward corruption (device noise) + D3PMLVBLoss forward and "
-                           "gradient, B=256 L=512 K=22 n_tokens=24, back-to-back launches",
+        lvb = {"workload": "protein-style step: batched forward corruption (device noise) + the training loop's loss, "
+                           "LVB + CE: (D3PMLVBLoss + 0.001 * CrossEntropyLoss) * n_tokens, forward and gradient in one "
+                           "launch, B=256 L=512 K=22 n_tokens=24, back-to-back launches",
                "ms_per_step": lms, "tokens_per_s": BP * LP / (lms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": l_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24, false> via d3pm_lvb_loss, back-to-back launches "
-                            "between two HIP events", "kernel_ms": lk_ms, "algorithmic_bytes_per_token": lbytes,
-                            "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false>")}}
+                            "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24, false, true> via "
+                            "d3pm_lvb_hybrid_loss, back-to-back launches between two HIP events", "kernel_ms": lk_ms,
+                            "kernel_ms_lvb_alone": lo_ms, "algorithmic_bytes_per_token": lbytes,
+                            "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false")}}
 
     # ---- secondary: the two loss kernels at eight times the batch (B = 2048: the global batch of the DDP
     # configuration on one GPU; 285 / 218 MB per launch, more than the 256 MiB Infinity Cache holds), where launch
@@ -711,9 +734,11 @@ def worker(args):
         wsbq = lib.d3pm_lvb_loss_workspace(BPb, LPb, KPb)
         wsq = torch.empty(max(wsbq // 8, 1), dtype=torch.float64, device=dev)
 
+        ceq = torch.empty(BPb, dtype=torch.float64, device=dev)
+
         def big_lvb():
-            check(lib.d3pm_lvb_loss(ptab.desc(), ptr(pq), LDPb, ptr(x0q), ptr(xtq), ptr(tq), None, BPb, LPb, 500, 0,
-                                    1.0 / BPb, ptr(perq), ptr(dq), ptr(wsq), wsbq, sp))
+            check(lib.d3pm_lvb_hybrid_loss(ptab.desc(), ptr(pq), LDPb, ptr(x0q), ptr(xtq), ptr(tq), None, BPb, LPb, 500,
+                                           0, float(LPb), LAMBDA * LPb, ptr(perq), ptr(ceq), ptr(dq), ptr(wsq), wsbq, sp))
         bl_ms = event_ms(big_lvb, 50, warm=5)
         del pq, dq
 
@@ -725,21 +750,29 @@ def worker(args):
         large = {"workload": f"the two loss kernels at B={BB}, L=512 (1 048 576 tokens per launch), back-to-back launches "
                              "between two HIP events",
                  "hybrid_loss": roof(BYTES_PER_TOKEN, BB * L, bh_ms, "k_hybrid_loss_tpl<32, true, 512> in 256-thread workgroups via d3pm_hybrid_loss"),
-                 "lvb_loss": roof(8 * LDPb + 16, BPb * LPb, bl_ms, "k_lvb_loss_tpl<22, 24, false> via d3pm_lvb_loss")}
+                 "lvb_loss": roof(8 * LDPb + 16, BPb * LPb, bl_ms, "k_lvb_loss_tpl<22, 24, false, true> (LVB + CE) via d3pm_lvb_hybrid_loss")}
 
     progress("sections done")
     if rank == 0:
-        achieved = BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9
+        # the roofline figure is the launch over ten rotating buffer sets (357 MB: every launch reads its rows from
+        # HBM proper); the same launch on one 35.7 MB working set, which the 256 MiB Infinity Cache serves, is kept
+        # beside it as *_cache_resident
+        achieved = BYTES_PER_TOKEN * B * L / (kern_rot_ms * 1e-3) / 1e9
         traffic = measured_traffic("k_hybrid_loss_pair32<true, false>")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": (traffic["source"] + " (a committed rocprofv3 --pmc pass of this command, not "
                                    "measured by this run)") if traffic else None,
-                "kernel": "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss, back-to-back launches between two HIP events",
-                "kernel_ms": kern_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
-                "note": "one 35.7 MB working set relaunched back to back stays in the 256 MiB Infinity Cache; "
-                        "frac_rotating_buffers is the same launch over 10 disjoint buffer sets (357 MB), "
-                        "i.e. served from HBM"}
+                "kernel": "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss, back-to-back launches over 10 "
+                          "rotating sets of inputs and outputs between two HIP events",
+                "kernel_ms": kern_rot_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
+                "tokens_per_launch": B * L,
+                "kernel_ms_cache_resident": kern_ms,
+                "frac_cache_resident": BYTES_PER_TOKEN * B * L / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "frac / kernel_ms: 10 disjoint buffer sets (357 MB) in rotation, i.e. rows served from HBM; "
+                        "*_cache_resident: one 35.7 MB working set relaunched back to back, which stays in the "
+                        "256 MiB Infinity Cache; `bench.py --roofline-only` launches exactly the rotating sequence "
+                        "(the program of the committed rocprofv3 kernel trace)"}
         if kern_replayed_ms:
             roof["kernel_ms_graph_replayed"] = kern_replayed_ms
             roof["frac_graph_replayed"] = BYTES_PER_TOKEN * B * L / (kern_replayed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -748,9 +781,6 @@ def worker(args):
             # and corruption (k_hybrid_loss_pair32<true, true>): 16 more bytes per token
             roof["kernel_ms_with_next_q_sample"] = kern_next_ms
             roof["frac_with_next_q_sample"] = (BYTES_PER_TOKEN + 16) * B * L / (kern_next_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if kern_rot_ms:
-            roof["kernel_ms_rotating_buffers"] = kern_rot_ms
-            roof["frac_rotating_buffers"] = BYTES_PER_TOKEN * B * L / (kern_rot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": METRIC, "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / n_timed * 1e3,
@@ -805,6 +835,9 @@ def main(argv=None):
     ap.add_argument("--no-pipeline", action="store_true",
                     help="two launches per step (corruption, loss) instead of the loss launch of step i carrying the "
                          "corruption of step i+1")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="launch only the sequence roofline.frac is quoted on (the dominant kernel over rotating "
+                         "buffers) and print its figure: the program of the committed rocprofv3 kernel trace")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "absorbing"])
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (reverse sampling, K=256 image configuration, protein-style loss, "

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     xt = clamp_index(xt, K);
     float e[LD];
     float tok_loss = 0, tok_ce = 0, add0 = 0, addt = 0;
-    if (branch == 1) {
+    auto from_q = [&]() {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
       if (live && !q) acc = (double)NAN;                       // no probabilities given: NaN, nothing is read
       if (live && q) {
@@ -470,12 +470,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
         // depth D for an MSA laid out [D,L,K]
         acc += s * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
       }
-      if constexpr (!HYB) {
-#pragma unroll
-        for (int j = 0; j < LD; ++j) e[j] = 0.0f;
-      }
-    }
-    if (branch != 1 || HYB) {
+    };
+    auto from_rows = [&]() {
       rows.deposit_flat(img, lane, ls);
       wave_lds_order();
       Img::read_row(img, lane, e);
@@ -618,6 +614,18 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
       }
       acc += live ? (double)tok_loss : 0.0;
       if constexpr (HYB) acc_ce += live ? (double)tok_ce : 0.0;
+    };
+    if constexpr (HYB) {
+      if (branch == 1) from_q();
+      from_rows();
+    } else {
+      if (branch == 1) {
+        from_q();
+#pragma unroll
+        for (int j = 0; j < LD; ++j) e[j] = 0.0f;
+      } else {
+        from_rows();
+      }
     }
     // gradient rows back through the image; the special classes are patched in the lane's own row
     Img::write_row(img, lane, e);

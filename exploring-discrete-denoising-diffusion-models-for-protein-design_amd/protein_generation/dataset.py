@@ -54,16 +54,23 @@ class Collater(object):
         sequences = [x[0] for x in data]
         names = [x[1] for x in data]
         assert len(sequences) == len(names)
+        out = self.collate_tokens(_tokens(self.tokenizer, sequences, self._dev()), noise)
+        return out if self.lean else out + (names,)
+
+    def collate_tokens(self, tokenized, noise=None):
+        """The same for sequences that are already tokenised ([B, L] int64, e.g. a data set kept on the device):
+        the tuple of ``__call__`` without the names."""
         dev = self._dev()
-        tokenized = _tokens(self.tokenizer, sequences, dev)
-        timesteps = torch.tensor([np.random.randint(1, self.num_steps) for _ in sequences], dtype=torch.long, device=dev)
+        tokenized = tokenized.to(device=dev, dtype=torch.int64)
+        timesteps = torch.tensor([np.random.randint(1, self.num_steps) for _ in range(tokenized.shape[0])],
+                                 dtype=torch.long, device=dev)
         tables = protein_tables(self.Q, self.Q_bar, device=dev)
         src, q_x = corrupt_batch(tables, tokenized, timesteps, noise, want_probs=not self.lean)
         if self.lean:
             return src, timesteps, tokenized
         one_hot = self.tokenizer.one_hot(tokenized)
         src_one_hot = self.tokenizer.one_hot(src)
-        return src, src_one_hot, timesteps, tokenized, one_hot, self.Q, self.Q_bar, q_x, names
+        return src, src_one_hot, timesteps, tokenized, one_hot, self.Q, self.Q_bar, q_x
 
 
 class CollaterMSA(object):

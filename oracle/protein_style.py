@@ -235,6 +235,41 @@ def collate_v2(tokens: torch.Tensor, t: int, num_steps: int, Q_bar: torch.Tensor
     return torch.stack(src).to(torch.long), torch.tensor(ts, dtype=torch.long), torch.stack(qx).to(torch.double)
 
 
+def collate(tokens: torch.Tensor, num_steps: int, Q_bar: torch.Tensor, expo: torch.Tensor, K: int = K_MSA):
+    """dataset.py:219-250 (``Collater.__call__``) on tokenised sequences [B,L]: per sequence, in order, one
+    ``np.random.randint(1, num_steps)`` (numpy's global generator) and one corruption with Q_bar[t]; the multinomial
+    draws [B,L,K] are passed in.  Returns (src [B,L], src_one_hot, timesteps [B], tokenized, one_hot, q_x)."""
+    src, ts, qx = [], [], []
+    for i in range(tokens.shape[0]):
+        t = np.random.randint(1, num_steps)
+        ts.append(t)
+        x_t, p = corrupt(one_hot(tokens[i], K), Q_bar[t], expo[i])
+        src.append(x_t)
+        qx.append(p)
+    src = torch.stack(src).to(torch.long)
+    return (src, one_hot(src, K), torch.tensor(ts, dtype=torch.long), tokens.to(torch.long), one_hot(tokens, K),
+            torch.stack(qx).to(torch.double))
+
+
+def collate_msa(tokens: torch.Tensor, num_steps: int, Q_bar: torch.Tensor, expo: torch.Tensor, K: int = K_MSA):
+    """dataset.py:262-300 (``CollaterMSA.__call__``) on tokenised MSAs [B,D,L]: one timestep per MSA, the flattened
+    [D*L] rows corrupted with it (draws [B,D*L,K] passed in); every MSA's probabilities are appended twice
+    (:287, :291), so q_x is [2B,D,L,K].  Returns (src [B,D,L], src_one_hot, timesteps [B], tokenized, tgt_one_hot,
+    q_x)."""
+    B, D, L = tokens.shape
+    src, ts, qx = [], [], []
+    for i in range(B):
+        t = np.random.randint(1, num_steps)
+        ts.append(t)
+        x_t, p = corrupt(one_hot(tokens[i], K).flatten(0, 1), Q_bar[t], expo[i])
+        src.append(x_t.reshape(D, L))
+        qx.append(p.reshape(D, L, K))
+        qx.append(p.reshape(D, L, K))
+    src = torch.stack(src).to(torch.long)
+    return (src, one_hot(src, K), torch.tensor(ts), tokens.to(torch.long), one_hot(tokens, K),
+            torch.stack(qx).to(torch.double))
+
+
 def mutant_scores(tokens: torch.Tensor, model, Q, Q_bar, steps: int, n_iter: int, minibatch: int, order_fn, t_fn,
                   expo_fn, K: int = K_MSA) -> np.ndarray:
     """utils.py:152-222 (the scoring loop of ``custom_mutant_matrix``) on

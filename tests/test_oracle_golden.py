@@ -230,6 +230,30 @@ def test_protein_collate_v2():
     assert g["timesteps_t500"].tolist() == [500, 499, 499, 499]      # the reference's decrement after the first
 
 
+def test_protein_collaters():
+    """Collater / CollaterMSA of the reference's dataset.py (executed as it is by tools/make_golden.py): timestep
+    draw order, corrupted tokens, probabilities, the one-hot tensors and the doubled q_x of the MSA collater."""
+    g = golden("protein_collaters")
+    qb, _ = pr.uniform_tables(22, 500, "sohl-dickstein")
+    toks = T_(g["tokens"])[:8]
+    np.random.seed(int(g["np_seed"]))
+    src, src_oh, ts, tgt, tgt_oh, qx = pr.collate(toks, 500, qb, T_(g["expo"]))
+    np.testing.assert_array_equal(ts.numpy(), g["timesteps"])
+    np.testing.assert_array_equal(src.numpy(), g["src"])
+    np.testing.assert_array_equal(tgt.numpy(), g["tokenized"])
+    np.testing.assert_array_equal(qx.numpy()[:, :4], g["q_rows"])
+    assert sha(src_oh.numpy()) == str(g["src_one_hot_sha256"]) and sha(tgt_oh.numpy()) == str(g["tgt_one_hot_sha256"])
+    msa = T_(g["tokens"])[:12, :60].reshape(3, 4, 60)
+    np.random.seed(int(g["msa_np_seed"]))
+    src, src_oh, ts, tgt, tgt_oh, qx = pr.collate_msa(msa, 500, qb, T_(g["msa_expo"]))
+    np.testing.assert_array_equal(ts.numpy(), g["msa_timesteps"])
+    np.testing.assert_array_equal(src.numpy(), g["msa_src"])
+    np.testing.assert_array_equal(tgt.numpy(), g["msa_tokenized"])
+    assert tuple(qx.shape) == tuple(g["msa_q_shape"]) == (6, 4, 60, 22)
+    np.testing.assert_array_equal(qx.numpy()[:, :, :3], g["msa_q_rows"])
+    assert sha(src_oh.numpy()) == str(g["msa_src_one_hot_sha256"])
+
+
 def _mutant_fixture():
     g = golden("protein_mutant_scores")
     rows = g["expo_rows"].tolist()

@@ -12,8 +12,8 @@ python - "$OUT" <<'P'
 import json, sys
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
-print("value %.3e %s  ms/step %.4f  frac %.3f  rotating %s  kernel_ms %.5f  timed_s %.4f" % (
-    d["value"], d["unit"], d["ms_per_step"], r["frac"], r.get("frac_rotating_buffers"), r["kernel_ms"], d["config"]["timed_seconds"]), " two-launch ms/step", d["config"].get("two_launches_per_step_ms_per_step"), " with-next kernel", r.get("kernel_ms_with_next_q_sample"), r.get("frac_with_next_q_sample"), " replayed", r.get("kernel_ms_graph_replayed"), r.get("frac_graph_replayed"))
+print("value %.3e %s  ms/step %.4f  frac %.3f  cache-resident %s  kernel_ms %.5f  timed_s %.4f" % (
+    d["value"], d["unit"], d["ms_per_step"], r["frac"], r.get("frac_cache_resident"), r["kernel_ms"], d["config"]["timed_seconds"]), " two-launch ms/step", d["config"].get("two_launches_per_step_ms_per_step"), " with-next kernel", r.get("kernel_ms_with_next_q_sample"), r.get("frac_with_next_q_sample"), " replayed", r.get("kernel_ms_graph_replayed"), r.get("frac_graph_replayed"))
 for k in ("absorbing", "reverse_sample", "image_k256", "protein_lvb"):
     s = d.get(k)
     if s:

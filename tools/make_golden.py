@@ -400,6 +400,57 @@ def part_protein():
                      f"expo_t{tcase}": Ec.numpy()})
     save("protein_collate_v2", **arrs)
 
+    # --- Collater / CollaterMSA (dataset.py:196-300) ------------------------------------------
+    # dataset.py parses its training alignment at import (a Colab path, :19, :119) and writes a FASTA beside the
+    # working directory: the module is executed as it is, with that one path served from a temporary alignment built
+    # from the generated sequences, in a temporary working directory.
+    import builtins
+    import importlib.util
+    tmpd = tempfile.mkdtemp()
+    a2m = os.path.join(tmpd, "train.a2m")
+    rows16 = fasta_tokens(16)
+    with open(a2m, "w") as f:
+        for i, r in enumerate(rows16):
+            f.write(f">SEQ_{i}/1-{len(r)}\n{tok.untokenize(r)}\n")
+    real_open = builtins.open
+
+    def open_redirect(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/content/drive/"):
+            path = a2m
+        return real_open(path, *a, **k)
+
+    cwd = os.getcwd()
+    os.chdir(tmpd)
+    builtins.open = open_redirect
+    try:
+        spec = importlib.util.spec_from_file_location("ref_dataset", os.path.join(REF, "protein_generation", "dataset.py"))
+        rds = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rds)
+    finally:
+        builtins.open = real_open
+        os.chdir(cwd)
+    seqs8 = [tok.untokenize(r) for r in rows16[:8]]
+    col = rds.Collater(tokenizer=tok, num_steps=500, Q=Qt, Q_bar=Qb)
+    np.random.seed(21); torch.manual_seed(901)
+    src, src_oh, tsv, tgt, tgt_oh, Qr, Qbr, qx, names = col([(s_, f"n{i}") for i, s_ in enumerate(seqs8)])
+    assert Qr is Qt and Qbr is Qb
+    torch.manual_seed(901)
+    Ec = torch.stack([torch.empty(len(seqs8[0]), K, dtype=torch.float64).exponential_(1) for _ in seqs8])
+    carr = dict(tokens=rows16, np_seed=np.array(21), src=src.numpy(), timesteps=tsv.numpy(), q_rows=qx.numpy()[:, :4],
+                expo=Ec.numpy(), names=np.array(names), src_one_hot_sha256=np.array(sha(src_oh.numpy())),
+                tgt_one_hot_sha256=np.array(sha(tgt_oh.numpy())), tokenized=tgt.numpy())
+    # MSAs: 3 alignments of 4 rows, first 60 columns
+    msas = [[tok.untokenize(r[:60]) for r in rows16[4 * m:4 * m + 4]] for m in range(3)]
+    colm = rds.CollaterMSA(tokenizer=tok, num_steps=500, Q=Qt, Q_bar=Qb, num_seqs=4)
+    np.random.seed(22); torch.manual_seed(902)
+    srcm, srcm_oh, tsm, tgtm, tgtm_oh, _, _, qxm = colm(msas)
+    torch.manual_seed(902)
+    Em = torch.stack([torch.empty(4 * 60, K, dtype=torch.float64).exponential_(1) for _ in msas])
+    carr.update(msa_np_seed=np.array(22), msa_src=srcm.numpy(), msa_timesteps=tsm.numpy(), msa_q_shape=np.array(qxm.shape),
+                msa_q_rows=qxm.numpy()[:, :, :3], msa_expo=Em.numpy(), msa_tokenized=tgtm.numpy(),
+                msa_src_one_hot_sha256=np.array(sha(srcm_oh.numpy())))
+    save("protein_collaters", **carr)
+
     # --- custom_mutant_matrix (utils.py:105-236) on a synthetic mutant list ----------------
     Lf, Tf = 24, 30
     Qb30, Qt30 = tok.q_uniform_schedule(num_steps=Tf, schedule="sohl-dickstein")

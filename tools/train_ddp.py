@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
 """Data-parallel training harness around the D3PM core: a ByteNet-like denoiser in
-stock PyTorch, the two-launch training step of this package for everything
-between data and logits gradient, DistributedDataParallel for the denoiser's
-gradients (the core itself has no parameters and no collective).
+stock PyTorch, this package for everything between data and logits gradient,
+DistributedDataParallel for the denoiser's gradients (the core itself has no
+parameters and no collective).
+
+--style protein (default) is the reference's protein training loop (Protein
+Generation Notebook cell-5 / cell-12): the lean Collater corrupts the batch on the
+device (t ~ randint(1, T) per sequence, x_t ~ q(x_t | x_0)), the denoiser maps
+[B, L] tokens to [B, L, n_tokens] logits, and the loss is
+(D3PMLVBLoss + lambda * CrossEntropyLoss) * n_tokens from one fused launch, K = 22,
+L = 263, 256 sequences per GPU.  --style image is the d3pm-style two-launch
+DiscreteDiffusion.training_step on [B, L, 1, 1] tokens.
 
     python tools/train_ddp.py --steps 30                              # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -67,7 +75,12 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--seq-len", type=int, default=263)
-    ap.add_argument("--bits", type=int, default=5, help="K = 2**bits classes")
+    ap.add_argument("--style", default="protein", choices=["protein", "image"])
+    ap.add_argument("--lam", type=float, default=0.001, help="weight of the cross-entropy term (both styles)")
+    ap.add_argument("--bits", type=int, default=5, help="--style image: K = 2**bits classes")
+    ap.add_argument("--dump", default=None,
+                    help="--style protein: save the last timed step's x0, x_t, t, logits, loss and dlogits of rank 0 "
+                         "to this .pt file")
     ap.add_argument("--d-model", type=int, default=256)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--backend", default="nccl",
@@ -79,6 +92,14 @@ def main(argv=None):
                          "process exits (0 = off)")
     args = ap.parse_args(argv)
 
+    try:
+        return run(args)
+    finally:
+        # armed by every phase() below: must not outlive this call (the caller may be a test process)
+        faulthandler.cancel_dump_traceback_later()
+
+
+def run(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -108,7 +129,8 @@ def main(argv=None):
     cdev = torch.device("cpu") if gloo else dev
 
     import d3pm_amd
-    K, T, B, L = 2 ** args.bits, 500, args.batch_per_gpu, args.seq_len
+    protein = args.style == "protein"
+    K, T, B, L = (22 if protein else 2 ** args.bits), 500, args.batch_per_gpu, args.seq_len
     torch.manual_seed(1234)                                   # same initial weights on every rank
     model = ByteNetLike(K, T, args.d_model, args.layers).to(dev)
     torch.cuda.synchronize()
@@ -130,12 +152,7 @@ def main(argv=None):
             g_.copy_(flat[off:off + g_.numel()].view_as(g_))
             off += g_.numel()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform",
-                                   num_bits=args.bits, transition_bands=None, model_prediction="x_start",
-                                   model_output="logits", loss_type="hybrid", hybrid_coeff=0.001, device=dev)
     torch.manual_seed(99 + rank)                              # different data and noise per rank
-    data = torch.randint(0, K, (B, L, 1, 1), device=dev)
-
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
     def model_fn(x, t):
@@ -145,12 +162,44 @@ def main(argv=None):
         ev[2].record()                                        # logits ready: the loss follows
         return out
 
+    if protein:
+        import numpy as np
+        from d3pm_amd.protein_generation.dataset import Collater
+        np.random.seed(99 + rank)                             # the collater draws its timesteps from numpy's generator
+        tok = d3pm_amd.Tokenizer()
+        Qb, Qt = tok.q_uniform_schedule(num_steps=T, device=dev)
+        collater = Collater(tokenizer=tok, num_steps=T, Q=Qt, Q_bar=Qb, device=dev, lean=True)
+        loss_fn = d3pm_amd.D3PMLVBLoss(tmax=T, tokenizer=tok, hybrid_coeff=args.lam)
+        data = torch.randint(0, K, (B, L), device=dev)        # tokenised sequences, resident on the device
+        last = {}
+
+        def forward_backward():
+            src, timesteps, tgt = collater.collate_tokens(data)            # dataset.py:219-250, one launch
+            outputs = model_fn(src, timesteps)                              # [B, L, n_tokens]
+            n_tokens = src.shape[0] * src.shape[1]                          # notebook cell-12
+            if args.dump:
+                outputs.retain_grad()
+            loss = loss_fn(None, None, outputs, tgt, None, timesteps, Qt, Qb, src=src, out_scale=n_tokens)
+            loss.backward()
+            last.update(x0=tgt, x_t=src, t=timesteps, logits=outputs, loss=loss.detach())
+            # per-sequence lvb + lambda * ce (not scaled by n_tokens), for the log line
+            return {"losses": (loss.detach() / n_tokens).reshape(1), "x_t": src, "t": timesteps}
+    else:
+        d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, T, "jsd"),
+                                       transition_mat_type="uniform", num_bits=args.bits, transition_bands=None,
+                                       model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                       hybrid_coeff=args.lam, device=dev)
+        data = torch.randint(0, K, (B, L, 1, 1), device=dev)
+
+        def forward_backward():
+            return d.training_step(model_fn, x_start=data)    # backward through the denoiser included
+
     def step(sync=True):
         opt.zero_grad(set_to_none=True)
         ev[0].record()
         ctx = net.no_sync() if (use_ddp and not sync) else contextlib.nullcontext()
         with ctx:
-            out = d.training_step(model_fn, x_start=data)     # backward through the denoiser included
+            out = forward_backward()
         if world > 1 and gloo and sync:
             average_grads_via_host()
         opt.step()
@@ -189,11 +238,20 @@ def main(argv=None):
     with torch.no_grad():
         logits = model(out["x_t"], out["t"]).detach()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    frozen = lambda x, t: logits
-    d.training_step(frozen, x_start=data, backward=False)
+    if protein:
+        if args.dump and rank == 0:
+            torch.save({k: v.detach().cpu() for k, v in last.items()} | {"dlogits": last["logits"].grad.detach().cpu(),
+                       "lam": args.lam}, args.dump)
+        lg = logits.requires_grad_(True)
+        fused = lambda: loss_fn(None, None, lg, data, None, out["t"], Qt, Qb, src=out["x_t"], out_scale=B * L)
+    else:
+        frozen = lambda x, t: logits
+        d.training_step(frozen, x_start=data, backward=False)
+        fused = lambda: d._fused(logits.requires_grad_(True), data, out["x_t"], out["t"], "hybrid")
+    fused()
     torch.cuda.synchronize(); e0.record()
     for _ in range(20):
-        d._fused(logits.requires_grad_(True), data, out["x_t"], out["t"], "hybrid")
+        fused()
     e1.record(); torch.cuda.synchronize()
     loss_ms = e0.elapsed_time(e1) / 20
     if world > 1:
@@ -210,7 +268,10 @@ def main(argv=None):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         spread = (hi - lo).abs() / hi.abs().clamp_min(1e-30)
     result = {
-        "what": "DDP training step: ByteNet-like denoiser (stock PyTorch) + D3PM training_step (this package)",
+        "what": ("DDP training step, protein style: lean Collater (device corruption) + ByteNet-like denoiser (stock "
+                 "PyTorch) + (D3PMLVBLoss + lambda * CE) * n_tokens from one fused launch" if protein else
+                 "DDP training step, image style: ByteNet-like denoiser (stock PyTorch) + DiscreteDiffusion.training_step"),
+        "style": args.style, "lambda": args.lam,
         "n_gpus": world, "backend": args.backend if world > 1 else None, "global_batch": B * world, "seq_len": L,
         "K": K, "denoiser": {"d_model": args.d_model, "layers": args.layers, "bf16": args.bf16,
                              "params": sum(p.numel() for p in model.parameters())},
@@ -218,15 +279,14 @@ def main(argv=None):
         "path_ms": {"corrupt_and_timestep_draw": corrupt_ms, "fused_loss_fwd_bwd": loss_ms},
         "path_share": (corrupt_ms + loss_ms) / ms,
         "allreduce_share": max(0.0, (ms - nosync_ms) / ms) if world > 1 else 0.0,
-        "first_step_loss_bits_per_dim": first,
-        "mean_loss_bits_per_dim": float(losses.item()),
+        "first_step_loss": first, "mean_loss": float(losses.item()),
+        "loss_unit": "lvb + lambda * ce, nats per sequence position" if protein else "bits per dimension",
         "weight_checksum_spread_over_ranks": float(spread.item())}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    faulthandler.cancel_dump_traceback_later()
     phase_done = f"[train_ddp rank {rank}] done"
     print(phase_done, file=sys.stderr, flush=True)
     return result
