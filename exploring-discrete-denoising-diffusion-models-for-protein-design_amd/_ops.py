@@ -1,9 +1,9 @@
 """``torch.ops.d3pm_mi355x``: the PyTorch-ROCm extension form of the boundary
 (``csrc/torch_ops.cpp``, a thin shim over the C ABI of libd3pm_hip.so).
 
-The facade's reference-shaped operators go through these ops; set-up (table
-building), the extended two-launch training step and the micro-benchmarks call
-the C ABI directly through ``_lib`` (ctypes).  Both libraries are built in-tree by
+Every call the facade makes goes through these ops (they make the tensors' device
+current, check shapes and allocate outputs); tests, the benchmark's kernel
+timings and foreign callers use the C ABI directly through ``_lib`` (ctypes).  Both libraries are built in-tree by
 ``__graft_entry__.build()``; importing this module without them raises."""
 from __future__ import annotations
 
@@ -21,8 +21,10 @@ if not os.path.exists(OPS_PATH):
 torch.ops.load_library(OPS_PATH)
 ops = torch.ops.d3pm_mi355x
 
-OP_NAMES = ("q_probs", "q_sample", "q_posterior_logits", "q_posterior_logits_backward", "hybrid_loss", "scale_rows_",
-            "p_sample", "prior_bpd", "lvb_loss", "lvb_reverse_step", "corrupt")
+OP_NAMES = ("q_probs", "q_sample", "q_sample_draw_t", "q_posterior_logits", "q_posterior_logits_backward", "hybrid_loss",
+            "hybrid_loss_step", "hybrid_loss_then_q_sample", "hybrid_loss_static_", "scale_rows_", "p_sample", "prior_bpd",
+            "logistic_logits", "logistic_logits_backward", "build_tables", "protein_uniform_tables", "cumprod",
+            "digest_f32", "digest_f64", "table_to_f32", "lvb_loss", "lvb_hybrid_loss", "lvb_reverse_step", "corrupt")
 
 
 def i64(x: int) -> int:

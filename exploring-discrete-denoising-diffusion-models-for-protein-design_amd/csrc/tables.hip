@@ -237,7 +237,7 @@ static int launch_chain(int K, int T, const double* mats, long st, long sr, long
 using namespace d3pm;
 
 extern "C" const char* d3pm_last_error(void) { return g_err; }
-extern "C" int d3pm_abi_version(void) { return 8; }
+extern "C" int d3pm_abi_version(void) { return 9; }
 
 extern "C" int d3pm_build_tables_f64(int kind, int K, int T, int bands, const double* betas, double* q_onestep,
                                      double* q_mats, void* stream) {

@@ -22,7 +22,6 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
-from .._lib import lib, check, ptr, stream_ptr, tok_bytes
 from .._ops import ops, i64
 from ..tables import ImageTables
 from . import utils
@@ -58,6 +57,17 @@ def _philox_ticket(device) -> tuple:
     return seed & 0xFFFFFFFFFFFFFFFF, off
 
 
+_MEAN_SCALE = {}
+
+
+def _mean_scale(B: int) -> float:
+    """float32(1) / float32(B): the upstream gradient `.mean()` hands every batch element."""
+    v = _MEAN_SCALE.get(B)
+    if v is None:
+        v = _MEAN_SCALE[B] = float(np.float32(1.0) / np.float32(max(B, 1)))
+    return v
+
+
 class StepResult(dict):
     """What ``training_step`` returns.  ``['loss']``, the batch mean, is reduced
     from ``['losses']`` whenever it is read (one small launch on the current
@@ -76,13 +86,9 @@ class _LogisticLogits(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, loc, log_scale, centers, eps):
-        K = centers.numel()
         loc_c, ls_c = loc.contiguous().float(), log_scale.contiguous().float()
         _lib.require_device(loc_c, ls_c, centers)
-        out = torch.empty(loc.shape + (K,), dtype=torch.float32, device=loc.device)
-        with torch.cuda.device(loc.device):
-            check(lib.d3pm_logistic_logits(ptr(loc_c), ptr(ls_c), ptr(centers), loc_c.numel(), K, eps, ptr(out),
-                                           stream_ptr()))
+        out = ops.logistic_logits(loc_c, ls_c, centers, eps)
         ctx.save_for_backward(loc_c, ls_c, centers)
         ctx.eps = eps
         return out
@@ -90,11 +96,7 @@ class _LogisticLogits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         loc, ls, centers = ctx.saved_tensors
-        g = grad.contiguous().float()
-        dloc, dls = torch.empty_like(loc), torch.empty_like(ls)
-        with torch.cuda.device(loc.device):
-            check(lib.d3pm_logistic_logits_backward(ptr(loc), ptr(ls), ptr(centers), ptr(g), loc.numel(),
-                                                    centers.numel(), ctx.eps, ptr(dloc), ptr(dls), stream_ptr()))
+        dloc, dls = ops.logistic_logits_backward(loc, ls, centers, grad.contiguous().float(), ctx.eps)
         return dloc, dls, None, None
 
 
@@ -104,16 +106,14 @@ class _FusedLoss(torch.autograd.Function):
     in place in backward only if the real upstream differs."""
 
     @staticmethod
-    def forward(ctx, logits, x0, x_t, t, tables, loss_type, lam, baked):
-        B = x0.shape[0]
-        K = tables.K
-        npos = x0.numel() // max(B, 1)
+    def forward(ctx, logits, x0, x_t, t, tables, loss_type, lam, baked, counter, advance):
         lg = logits.contiguous()
         if lg.dtype != torch.float32:
             lg = lg.float()
         want_grad = ctx.needs_input_grad[0]
-        loss, _, _, dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, float(lam), float(baked), None,
-                                         want_grad)
+        # (counter: the Philox counter of the corruption launch, advanced by this launch)
+        loss, dl = ops.hybrid_loss_step(*tables.op_args(), lg, x0, x_t, t, loss_type, float(lam), float(baked), want_grad,
+                                        None, counter, int(advance))
         if not want_grad:
             dl = None
         ctx.dl, ctx.baked, ctx.shape, ctx.dtype = dl, float(baked), logits.shape, logits.dtype
@@ -125,23 +125,20 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, g):
         dl = ctx.dl
         if dl is None:
-            return (None,) * 8
+            return (None,) * 10
         g = g.contiguous().float()
-        B = g.shape[0]
         if getattr(ctx, "spent", False):
             # the first backward gave its buffer away (rescaled in place): recompute the gradient with this
             # upstream gradient passed to the kernel
             lg, x0, x_t, t, tables, loss_type, lam = ctx.again
-            with torch.cuda.device(lg.device):
-                dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, lam, 1.0, g, True)[3]
+            dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, lam, 1.0, g, True)[3]
         else:
             ctx.spent = True
-            with torch.cuda.device(dl.device):
-                ops.scale_rows_(dl, g, ctx.baked)
+            ops.scale_rows_(dl, g, ctx.baked)
         out = dl.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)
-        return out, None, None, None, None, None, None, None
+        return (out,) + (None,) * 9
 
 
 class _PosteriorFromLogits(torch.autograd.Function):
@@ -157,8 +154,7 @@ class _PosteriorFromLogits(torch.autograd.Function):
         lg = xs.contiguous()
         if lg.dtype != torch.float32:
             lg = lg.float()
-        with torch.cuda.device(x_t.device):
-            out = ops.q_posterior_logits(*tables.op_args(), lg, True, x_t, t)
+        out = ops.q_posterior_logits(*tables.op_args(), lg, True, x_t, t)
         ctx.save_for_backward(lg, t)
         ctx.tables, ctx.dims, ctx.dtype = tables, (B, npos), xs.dtype
         return out
@@ -170,8 +166,7 @@ class _PosteriorFromLogits(torch.autograd.Function):
         K = tables.K
         g = g.contiguous().float()
         if tables.structured:
-            with torch.cuda.device(lg.device):
-                gz = ops.q_posterior_logits_backward(*tables.op_args(), lg, t, g)
+            gz = ops.q_posterior_logits_backward(*tables.op_args(), lg, t, g)
         else:
             tl = t.long()
             pi = torch.softmax(lg.reshape(B, npos, K), dim=-1)
@@ -230,13 +225,8 @@ class DiscreteDiffusion:
         self.betas = betas.detach().to(dtype=torch.float64)
         self.num_timesteps = T = self.betas.shape[0]
         K = self.num_pixel_vals
-        with torch.cuda.device(self.device):
-            b_dev = self.betas.to(self.device).contiguous()
-            onestep = torch.empty((T, K, K), dtype=torch.float64, device=self.device)
-            q_mats = torch.empty((T, K, K), dtype=torch.float64, device=self.device)
-            bands = -1 if transition_bands is None else int(transition_bands)
-            check(lib.d3pm_build_tables_f64(_lib.KIND[transition_mat_type], K, T, bands, ptr(b_dev), ptr(onestep),
-                                            ptr(q_mats), stream_ptr()))
+        bands = -1 if transition_bands is None else int(transition_bands)
+        onestep, q_mats = ops.build_tables(self.betas.to(self.device).contiguous(), _lib.KIND[transition_mat_type], K, bands)
         # q(x_t | x_start) and the transposed one-step matrices, as in :90,:97
         self.q_mats = q_mats
         self.transpose_q_onestep_mats = onestep.permute(0, 2, 1)
@@ -281,8 +271,7 @@ class DiscreteDiffusion:
         tb = self.tables()
         _lib.require_device(x)
         t = _as_tokens(t)
-        with torch.cuda.device(x.device):
-            return ops.q_probs(*tb.op_args(), x, t)
+        return ops.q_probs(*tb.op_args(), x, t)
 
     def q_sample(self, x_start, t, noise=None, noise_kind: str = "uniform", rng=None):
         """x_t ~ q(x_t | x_start) by Gumbel-max (:266-285); int64.
@@ -309,8 +298,7 @@ class DiscreteDiffusion:
             assert noise.shape == x.shape + (tb.K,), noise.shape
             kind = _lib.NOISE[noise_kind]
             noise = noise.contiguous().float()
-        with torch.cuda.device(x.device):
-            return ops.q_sample(*tb.op_args(), x, t, noise, kind, i64(seed), i64(off), off_dev)
+        return ops.q_sample(*tb.op_args(), x, t, noise, kind, i64(seed), i64(off), off_dev)
 
     # ------------------------------------------------------------------ posterior
     def _get_logits_from_logistic_pars(self, loc, log_scale):
@@ -338,8 +326,7 @@ class DiscreteDiffusion:
         tb = self.tables()
         if x_start_logits and torch.is_grad_enabled() and x_start.requires_grad:
             return _PosteriorFromLogits.apply(x_start, xt, t, tb)
-        with torch.cuda.device(xt.device):
-            return ops.q_posterior_logits(*tb.op_args(), xs.detach(), bool(x_start_logits), xt, t)
+        return ops.q_posterior_logits(*tb.op_args(), xs.detach(), bool(x_start_logits), xt, t)
 
     def _denoiser_logits(self, model_fn, x, t):
         out = model_fn(x, t)
@@ -393,9 +380,8 @@ class DiscreteDiffusion:
             assert noise.shape == lg.shape, noise.shape
             kind = _lib.NOISE[noise_kind]
             noise = noise.contiguous().float()
-        with torch.cuda.device(xt.device):
-            sample, probs = ops.p_sample(*tb.op_args(), lg, xt, t, noise, kind, i64(seed), i64(off), off_dev,
-                                         bool(want_probs))
+        sample, probs = ops.p_sample(*tb.op_args(), lg, xt, t, noise, kind, i64(seed), i64(off), off_dev,
+                                     bool(want_probs))
         return sample, (probs if want_probs else None)
 
     @torch.no_grad()
@@ -433,16 +419,15 @@ class DiscreteDiffusion:
         return (x_init, x) if return_x_init else x
 
     # ------------------------------------------------------------------ losses
-    def _fused(self, pred, x_start, x_t, t, loss_type: str, baked: Optional[float] = None):
+    def _fused(self, pred, x_start, x_t, t, loss_type: str, baked: Optional[float] = None, counter=None, advance=0):
         x0, xt, t = _as_tokens(x_start), _as_tokens(x_t), _as_tokens(t)
         _lib.require_device(pred, x0, xt)
         assert pred.shape == x0.shape + (self.num_pixel_vals,), pred.shape
         B = x0.shape[0]
         if baked is None:
-            baked = float(np.float32(1.0) / np.float32(max(B, 1)))    # upstream of `.mean()`
-        with torch.cuda.device(x0.device):
-            return _FusedLoss.apply(pred, x0, xt, t, self.tables(), _lib.LOSS[loss_type], self.hybrid_coeff or 0.0,
-                                    baked)
+            baked = _mean_scale(B)                                    # upstream of `.mean()`
+        return _FusedLoss.apply(pred, x0, xt, t, self.tables(), _lib.LOSS[loss_type], self.hybrid_coeff or 0.0, baked,
+                                counter, advance)
 
     def vb_terms_bpd(self, model_fn, *, x_start, x_t, t):
         """Variational-bound terms in bits/dim (:462-489): (vb[B], pred logits)."""
@@ -462,8 +447,7 @@ class DiscreteDiffusion:
         _lib.require_device(x)
         tb = self.tables()
         B, npos = self._dims(x)
-        with torch.cuda.device(x.device):
-            return ops.prior_bpd(*tb.op_args(), x, self.transition_mat_type == "absorbing")
+        return ops.prior_bpd(*tb.op_args(), x, self.transition_mat_type == "absorbing")
 
     def cross_entropy_start(self, x_start, pred_x_start_logits):
         """Cross entropy of x_start under the predicted logits, bits/dim (:527-542)."""
@@ -479,13 +463,22 @@ class DiscreteDiffusion:
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         B = x_start.shape[0]
-        if t is None:
-            t = torch.randint(0, self.num_timesteps, (B,), dtype=torch.int32, device=self.device)
-        x_t = self.q_sample(x_start=x_start, t=t, noise=noise, noise_kind=noise_kind, rng=rng)
+        counter, advance = None, 0
+        if t is None and noise is None:
+            # timesteps and noisy tokens from one launch on the device Philox stream (:549-556); with an explicit
+            # counter the loss launch below advances it, so a captured step needs no bookkeeping launch
+            c = self.corrupt_step(x_start=x_start, rng=rng)
+            t, x_t = c["t"], c["x_t"]
+            if rng is not None and len(rng) == 2:
+                counter, advance = rng[1], 4
+        else:
+            if t is None:
+                t = torch.randint(0, self.num_timesteps, (B,), dtype=torch.int32, device=self.device)
+            x_t = self.q_sample(x_start=x_start, t=t, noise=noise, noise_kind=noise_kind, rng=rng)
         pred = self._denoiser_logits(model_fn, x_t, t)
         if self.model_prediction != "x_start":
             raise NotImplementedError(self.model_prediction)
-        losses = self._fused(pred, x_start, x_t, t, self.loss_type)
+        losses = self._fused(pred, x_start, x_t, t, self.loss_type, counter=counter, advance=advance)
         assert losses.shape == t.shape
         return losses
 
@@ -536,12 +529,8 @@ class DiscreteDiffusion:
             assert counter.dtype == torch.int64 and counter.is_cuda and counter.numel() == 1
         else:
             seed, off = _philox_ticket(dev)
-        t = torch.empty(B, dtype=torch.int32, device=dev)
-        x_t = torch.empty(x0.shape, dtype=torch.int64, device=dev)
         mean = torch.empty((), dtype=torch.float32, device=dev) if device_mean else None   # zeroed by this launch
-        with torch.cuda.device(dev):
-            check(lib.d3pm_q_sample_draw_t(tb.desc(), ptr(x0), tok_bytes(x0), B, npos, seed, off, ptr(counter), ptr(mean),
-                                           ptr(t), ptr(x_t), stream_ptr()))
+        t, x_t = ops.q_sample_draw_t(*tb.op_args(), x0, i64(seed), i64(off), counter, mean)
         return {"t": t, "x_t": x_t, "mean": mean, "counter": counter, "seed": seed}
 
     def loss_step(self, model_fn, *, x_start, corrupted, backward=True, advance=4, prefetch=None):
@@ -567,12 +556,13 @@ class DiscreteDiffusion:
         if lg.dtype != torch.float32:
             lg = lg.float()
         want_grad = backward and pred.requires_grad
-        losses = torch.empty(B, dtype=torch.float32, device=dev)
-        dl = torch.empty_like(lg) if want_grad else None
-        ws_bytes = lib.d3pm_hybrid_loss_workspace(B, npos, tb.K)
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
         nxt = None
-        if prefetch is not None:
+        scale = _mean_scale(B)
+        lt, lam = _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0)
+        if prefetch is None:
+            losses, dl = ops.hybrid_loss_step(*tb.op_args(), lg, x0, x_t, t, lt, lam, scale, want_grad, mean, counter,
+                                              int(advance) if counter is not None else 0)
+        else:
             assert mean is None and (counter is None or int(advance) == 0), \
                 "a launch that corrupts the next batch only reads the counter and keeps no device mean"
             nx0 = _as_tokens(prefetch["x_start"])
@@ -582,22 +572,9 @@ class DiscreteDiffusion:
                 seed, off = int(corrupted["seed"]), int(prefetch.get("offset", 0))
             else:
                 seed, off = _philox_ticket(dev)
-            nxt = {"t": torch.empty(B, dtype=torch.int32, device=dev),
-                   "x_t": torch.empty(x0.shape, dtype=torch.int64, device=dev), "mean": None, "counter": counter,
-                   "seed": seed}
-        with torch.cuda.device(dev):
-            scale = float(np.float32(1.0) / np.float32(max(B, 1)))
-            if nxt is None:
-                check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
-                                           _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0), scale, None, None,
-                                           None, ptr(losses), ptr(dl), ptr(mean), ptr(counter),
-                                           int(advance) if counter is not None else 0, ptr(ws), ws_bytes, stream_ptr()))
-            else:
-                check(lib.d3pm_hybrid_loss_then_q_sample(
-                    tb.desc(), ptr(lg), tb.K, ptr(x0), tok_bytes(x0), ptr(x_t), 8, ptr(t), 4, B, npos,
-                    _lib.LOSS[self.loss_type], float(self.hybrid_coeff or 0.0), scale, None, None, None, ptr(losses),
-                    ptr(dl), ptr(ws), ws_bytes, ptr(nx0), tok_bytes(nx0), seed, off, ptr(counter), ptr(nxt["t"]),
-                    ptr(nxt["x_t"]), stream_ptr()))
+            losses, dl, nt, nxt_tokens = ops.hybrid_loss_then_q_sample(*tb.op_args(), lg, x0, x_t, t, lt, lam, scale,
+                                                                       want_grad, nx0, i64(seed), i64(off), counter)
+            nxt = {"t": nt, "x_t": nxt_tokens, "mean": None, "counter": counter, "seed": seed}
         if want_grad:
             holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
             del dl

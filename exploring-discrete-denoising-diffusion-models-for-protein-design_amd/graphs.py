@@ -50,7 +50,7 @@ class GraphedTrainingLosses:
             self.loss.backward()
 
     def _body(self):
-        self.counter.add_(4)
+        # (the loss launch advances the Philox counter: no bookkeeping launch in the graph)
         losses = self.diffusion.training_losses(self.model_fn, x_start=self.x_start, rng=(self.seed, self.counter))
         self.losses = losses
         return losses.mean()

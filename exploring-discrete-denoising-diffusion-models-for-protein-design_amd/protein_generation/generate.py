@@ -40,9 +40,8 @@ def reverse_step(tables, predictions, x_t, t, noise=None, last_class_div=1.0, ex
         seed, off, counter = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]), rng[2]
     else:
         seed, off = _philox_ticket(x_t.device)
-    with torch.cuda.device(x_t.device):
-        return ops.lvb_reverse_step(*tables.op_args(), pr, x_t, t, noise, i64(seed), i64(off), counter,
-                                    float(last_class_div), int(exclude_last_prefix))
+    return ops.lvb_reverse_step(*tables.op_args(), pr, x_t, t, noise, i64(seed), i64(off), counter,
+                                float(last_class_div), int(exclude_last_prefix))
 
 
 def generate_d3pm(model, tokenizer, Q, Q_bar, timesteps, seq_len, device, batch_size=3, x_init=None, noise_fn=None):

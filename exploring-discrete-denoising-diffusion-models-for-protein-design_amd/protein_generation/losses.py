@@ -76,11 +76,9 @@ class _LVB(torch.autograd.Function):
             # the first backward gave its buffer away (rescaled in place): recompute with unit scale
             pr, x0, x_t, t, q, tables, tmax, msa, lam = ctx.again
             baked = 1.0
-            with torch.cuda.device(pr.device):
-                dp = _LVB._run(pr, x0, x_t, t, q, tables, tmax, msa, 1.0, lam, True)[2]
+            dp = _LVB._run(pr, x0, x_t, t, q, tables, tmax, msa, 1.0, lam, True)[2]
         ctx.spent = True
-        with torch.cuda.device(dp.device):
-            ops.scale_rows_(dp, g, baked)
+        ops.scale_rows_(dp, g, baked)
         out = dp.view(ctx.shape)
         if out.dtype != ctx.dtype:
             out = out.to(ctx.dtype)
@@ -110,8 +108,7 @@ def _lvb_forward(self, src_onehot, q, predictions, tgt, tgt_onehot, timestep, Q,
     baked = scale if self.evaluation else float(np.float32(scale) / np.float32(max(B, 1)))
     depth = int(x0.shape[1]) if msa else 0            # [B, D, L]: MSA depth
     lam = None if self.hybrid_coeff is None else float(self.hybrid_coeff)
-    with torch.cuda.device(dev):
-        comb, ce = _LVB.apply(predictions, x0, x_t, t, qd, tables, self.tmax, depth, baked, lam)
+    comb, ce = _LVB.apply(predictions, x0, x_t, t, qd, tables, self.tmax, depth, baked, lam)
     self.ce_seq = ce if lam is not None else None
     if self.evaluation:
         return comb if out_scale is None else comb * scale                # losses.py:89-90

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._lib import lib, check, ptr, stream_ptr
+from .._ops import ops, i64
 from ..tables import ProteinTables
 from .constants import PROTEIN_ALPHABET, MSA_AAS, ALL_AAS, GAP
 
@@ -26,12 +26,7 @@ def cumprod_matrix(a):
     stack = a if torch.is_tensor(a) else torch.stack(list(a))
     dev = stack.device if stack.is_cuda else _default_device()
     stack = stack.to(device=dev, dtype=torch.float64)
-    T, K = stack.shape[0], stack.shape[1]
-    out = torch.empty((T, K, K), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.d3pm_cumprod_f64(K, T, ptr(stack), stack.stride(0), stack.stride(1), stack.stride(2), ptr(out),
-                                   stream_ptr()))
-    return list(out.unbind(0))
+    return list(ops.cumprod(stack).unbind(0))
 
 
 def _beta_schedule(num_steps, start=1e-5, end=0.999, schedule="linear"):
@@ -74,9 +69,7 @@ def corrupt_batch(tables: ProteinTables, x0, t, noise=None, want_probs=False):
     else:
         noise = noise.to(device=x0.device, dtype=torch.float64).contiguous()
         assert noise.shape == x0.shape + (tables.K,), noise.shape
-    from .._ops import ops, i64
-    with torch.cuda.device(x0.device):
-        x_t, probs = ops.corrupt(*tables.op_args(), x0, t, noise, i64(seed), i64(off), bool(want_probs))
+    x_t, probs = ops.corrupt(*tables.op_args(), x0, t, noise, i64(seed), i64(off), bool(want_probs))
     return x_t, (probs if want_probs else None)
 
 
@@ -106,12 +99,7 @@ class Tokenizer(object):
         col = torch.ones((K, K)) / K * betas.view(T, 1, 1)           # [T,K,K] float32
         off = col[:, 0, 0].contiguous()
         norm = torch.stack([1 - col[i].sum(axis=0)[0] for i in range(T)])
-        Q_t = torch.empty((T, K, K), dtype=torch.float64, device=dev)
-        Q_prod = torch.empty_like(Q_t)
-        off_d, norm_d = off.to(dev), norm.contiguous().to(dev)     # named: must outlive the launch
-        with torch.cuda.device(dev):
-            check(lib.d3pm_protein_uniform_tables_f64(K, T, ptr(off_d), ptr(norm_d), ptr(Q_t), ptr(Q_prod),
-                                                      stream_ptr()))
+        Q_t, Q_prod = ops.protein_uniform_tables(off.to(dev), norm.contiguous().to(dev), K)
         return Q_prod, Q_t
 
     def tokenize(self, seq):

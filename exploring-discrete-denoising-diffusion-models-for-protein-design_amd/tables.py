@@ -14,7 +14,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import lib, check, ptr, stream_ptr
+from ._lib import ptr
+from ._ops import ops
 
 
 def _strides3(t: torch.Tensor) -> Tuple[int, int, int]:
@@ -44,27 +45,15 @@ class ImageTables:
             q_onestep = q_onestep.permute(0, 2, 1)       # back to [t, from, to], no copy
         self._keep = (q_mats, q_onestep)
         T, K = self.T, self.K
-        with torch.cuda.device(self.device):
-            s = stream_ptr()
-            self.qbar_digest = torch.empty((T, 8, K), dtype=torch.float32, device=self.device)
-            self.qone_digest = torch.empty((T, 8, K), dtype=torch.float32, device=self.device)
-            viol = torch.zeros(2, dtype=torch.int32, device=self.device)
-            check(lib.d3pm_digest_f32(ptr(q_mats), *_strides3(q_mats), T, K, self.eps, ptr(self.qbar_digest),
-                                      viol.data_ptr(), s))
-            check(lib.d3pm_digest_f32(ptr(q_onestep), *_strides3(q_onestep), T, K, self.eps,
-                                      ptr(self.qone_digest), viol.data_ptr() + 4, s))
-            self.violations = tuple(int(v) for v in viol.tolist())     # one sync, at set-up
-            self.structured = (self.violations == (0, 0)) and not force_dense
-            self.qbar = self.qoneT = self.qbarT = None
-            if not self.structured:
-                self.qbar = torch.empty((T, K, K), dtype=torch.float32, device=self.device)
-                self.qoneT = torch.empty_like(self.qbar)
-                self.qbarT = torch.empty_like(self.qbar)
-                check(lib.d3pm_table_to_f32(ptr(q_mats), *_strides3(q_mats), T, K, ptr(self.qbar), s))
-                qT = q_mats.permute(0, 2, 1)
-                check(lib.d3pm_table_to_f32(ptr(qT), *_strides3(qT), T, K, ptr(self.qbarT), s))
-                oT = q_onestep.permute(0, 2, 1)
-                check(lib.d3pm_table_to_f32(ptr(oT), *_strides3(oT), T, K, ptr(self.qoneT), s))
+        self.qbar_digest, v0 = ops.digest_f32(q_mats, self.eps)
+        self.qone_digest, v1 = ops.digest_f32(q_onestep, self.eps)
+        self.violations = (int(v0.item()), int(v1.item()))               # one sync each, at set-up
+        self.structured = (self.violations == (0, 0)) and not force_dense
+        self.qbar = self.qoneT = self.qbarT = None
+        if not self.structured:
+            self.qbar = ops.table_to_f32(q_mats)
+            self.qbarT = ops.table_to_f32(q_mats.permute(0, 2, 1))
+            self.qoneT = ops.table_to_f32(q_onestep.permute(0, 2, 1))
         self._desc = _lib.TablesF32(K, T, int(self.structured), self.eps, ptr(self.qbar_digest),
                                     ptr(self.qone_digest), ptr(self.qbar), ptr(self.qoneT), ptr(self.qbarT))
 
@@ -73,12 +62,13 @@ class ImageTables:
 
     def op_args(self):
         """Leading arguments of the torch.ops.d3pm_mi355x image-style operators."""
-        e = getattr(self, "_empty", None)
-        if e is None:
-            e = self._empty = torch.empty(0, dtype=torch.float32, device=self.device)
-        return ([self.qbar_digest, self.qone_digest, e if self.qbar is None else self.qbar,
-                 e if self.qoneT is None else self.qoneT, e if self.qbarT is None else self.qbarT],
-                self.K, self.T, bool(self.structured), self.eps)
+        a = getattr(self, "_op_args", None)
+        if a is None:
+            e = torch.empty(0, dtype=torch.float32, device=self.device)
+            a = self._op_args = ([self.qbar_digest, self.qone_digest, e if self.qbar is None else self.qbar,
+                                  e if self.qoneT is None else self.qoneT, e if self.qbarT is None else self.qbarT],
+                                 self.K, self.T, bool(self.structured), self.eps)
+        return a
 
 
 class ProteinTables:
@@ -96,16 +86,9 @@ class ProteinTables:
         self.device = Q.device
         self._keep = (Q, Q_bar)
         T, K = self.T, self.K
-        with torch.cuda.device(self.device):
-            s = stream_ptr()
-            self.qbar_digest = torch.empty((T, 4, K), dtype=torch.float64, device=self.device)
-            self.qone_digest = torch.empty((T, 4, K), dtype=torch.float64, device=self.device)
-            viol = torch.zeros(2, dtype=torch.int32, device=self.device)
-            check(lib.d3pm_digest_f64(ptr(Q_bar), *_strides3(Q_bar), T, K, self.RTOL, ptr(self.qbar_digest),
-                                      viol.data_ptr(), s))
-            check(lib.d3pm_digest_f64(ptr(Q), *_strides3(Q), T, K, self.RTOL, ptr(self.qone_digest),
-                                      viol.data_ptr() + 4, s))
-            self.violations = tuple(int(v) for v in viol.tolist())
+        self.qbar_digest, v0 = ops.digest_f64(Q_bar, self.RTOL)
+        self.qone_digest, v1 = ops.digest_f64(Q, self.RTOL)
+        self.violations = (int(v0.item()), int(v1.item()))
         if self.violations != (0, 0):
             raise NotImplementedError(
                 "protein-style kernels need column-structured transition tables (uniform schedule); "

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, n), f"{n} declared in include/d3pm_hip.h but not exported"
     # and the binding lists exactly the header's functions
     assert sorted(pkg._lib.SIGNATURES) == names
-    assert pkg._lib.lib.d3pm_abi_version() == 8
+    assert pkg._lib.lib.d3pm_abi_version() == 9
 
 
 def test_torch_ops_registered(pkg):

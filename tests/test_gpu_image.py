@@ -1024,3 +1024,66 @@ def test_dense_q_sample_device_noise_distribution(pkg, bits):
         q = d.q_probs(x0[:1, :1], t[:1]).cpu().numpy().reshape(K).astype(np.float64) + 1e-6
         q /= q.sum()
         assert (np.abs(freq - q) < 5 * np.sqrt(q * (1 - q) / n) + 2e-6).all(), (bits, tval, np.abs(freq - q).max())
+
+
+
+def test_operators_reject_mis_shaped_calls(pkg):
+    """torch.ops.d3pm_mi355x is a public boundary of its own: a call whose tensors do not describe one batch must
+    raise before a pointer reaches the library (one case per operator family), and a well-formed call works without
+    the caller making the device current."""
+    from d3pm_amd._ops import ops
+    from d3pm_amd.tables import protein_tables
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, 20, "jsd"), transition_mat_type="uniform", num_bits=3,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    tb = d.tables()
+    B, L, K = 4, 6, 8
+    x0 = torch.randint(0, K, (B, L), device=DEV)
+    t = torch.randint(0, 20, (B,), device=DEV)
+    lg = torch.randn(B, L, K, device=DEV)
+    ok = ops.hybrid_loss(*tb.op_args(), lg, x0, x0, t, 2, 0.001, 0.25, None, True)
+    assert ok[0].shape == (B,) and ok[3].shape == lg.shape
+    bad_t, bad_x, bad_lg = t[:3].contiguous(), x0[:, :5].contiguous(), lg[:, :5].contiguous()
+    cases = [
+        lambda: ops.q_probs(*tb.op_args(), x0, bad_t),
+        lambda: ops.q_sample(*tb.op_args(), x0, t, torch.rand(B, L, K - 1, device=DEV), 0, 0, 0, None),
+        lambda: ops.q_sample_draw_t(*tb.op_args(), x0, 0, 0, torch.zeros(2, dtype=torch.int64, device=DEV), None),
+        lambda: ops.q_posterior_logits(*tb.op_args(), bad_x, False, x0, t),
+        lambda: ops.q_posterior_logits(*tb.op_args(), bad_lg, True, x0, t),
+        lambda: ops.q_posterior_logits_backward(*tb.op_args(), lg, t, bad_lg),
+        lambda: ops.hybrid_loss(*tb.op_args(), bad_lg, x0, x0, t, 2, 0.001, 0.25, None, True),
+        lambda: ops.hybrid_loss(*tb.op_args(), lg, x0, bad_x, t, 2, 0.001, 0.25, None, True),
+        lambda: ops.hybrid_loss(*tb.op_args(), lg, x0, x0, t, 2, 0.001, 0.25, torch.ones(B + 1, device=DEV), True),
+        lambda: ops.hybrid_loss_step(*tb.op_args(), lg, x0, x0, bad_t, 2, 0.001, 0.25, True, None, None, 0),
+        lambda: ops.hybrid_loss_then_q_sample(*tb.op_args(), lg, x0, x0, t, 2, 0.001, 0.25, True, bad_x, 0, 0, None),
+        lambda: ops.hybrid_loss_static_(*tb.op_args(), lg, x0, x0, t, 2, 0.001, 0.25, torch.empty(B - 1, device=DEV), None),
+        lambda: ops.scale_rows_(torch.empty(7, device=DEV), torch.ones(2, device=DEV), 1.0),
+        lambda: ops.p_sample(*tb.op_args(), lg, x0, bad_t, None, 2, 0, 0, None, False),
+        lambda: ops.logistic_logits(torch.zeros(5, device=DEV), torch.zeros(4, device=DEV), torch.linspace(-1, 1, 8).to(DEV), 1e-6),
+        lambda: ops.logistic_logits_backward(torch.zeros(5, device=DEV), torch.zeros(5, device=DEV),
+                                             torch.linspace(-1, 1, 8).to(DEV), torch.zeros(5, 7, device=DEV), 1e-6),
+        lambda: ops.digest_f32(torch.zeros(3, 4, 5, dtype=torch.float64, device=DEV), 1e-6),
+        lambda: ops.cumprod(torch.zeros(3, 4, dtype=torch.float64, device=DEV)),
+        # a float32 digest with the four rows of an older layout: read past its end if it were accepted
+        lambda: ops.q_probs([tb.qbar_digest[:, :4].contiguous(), tb.qone_digest] + list(tb.op_args()[0][2:]), K, 20, True,
+                            1e-6, x0, t),
+    ]
+    tok = pkg.Tokenizer()
+    Qb, Qt = tok.q_uniform_schedule(num_steps=30, device=DEV)
+    pt = protein_tables(Qt, Qb)
+    xp = torch.randint(0, 22, (B, L), device=DEV)
+    tp = torch.randint(1, 30, (B,), device=DEV)
+    pp = torch.randn(B, L, 24, device=DEV)
+    assert ops.lvb_loss(*pt.op_args(), pp, xp, xp, tp, None, 30, 0, 0.25, True)[0].shape == (B,)
+    cases += [
+        lambda: ops.lvb_loss(*pt.op_args(), pp[:, :5].contiguous(), xp, xp, tp, None, 30, 0, 0.25, True),
+        lambda: ops.lvb_loss(*pt.op_args(), pp, xp, xp, tp, torch.zeros(B, L, 21, dtype=torch.float64, device=DEV), 30, 0, 0.25, True),
+        lambda: ops.lvb_hybrid_loss(*pt.op_args(), pp, xp, xp[:, :5].contiguous(), tp, None, 30, 0, 0.25, 0.1, True),
+        lambda: ops.lvb_reverse_step(*pt.op_args(), pp, xp, tp[:2].contiguous(), None, 0, 0, None, 1.0, 0),
+        lambda: ops.corrupt(*pt.op_args(), xp, tp[:2].contiguous(), None, 0, 0, False),
+        lambda: ops.corrupt(pt.qbar_digest[:, :2].contiguous(), pt.qone_digest, 22, 30, xp, tp, None, 0, 0, False),
+    ]
+    for i, call in enumerate(cases):
+        with pytest.raises((ValueError, RuntimeError)):
+            call()
+            pytest.fail(f"mis-shaped call {i} was accepted")
