@@ -44,6 +44,7 @@ SIGNATURES = {
     "d3pm_cumprod_f64": (_I, [_I, _I, _P, _L, _L, _L, _P, _P]),
     "d3pm_digest_f32": (_I, [_P, _L, _L, _L, _I, _I, _F, _P, _P, _P]),
     "d3pm_digest_f64": (_I, [_P, _L, _L, _L, _I, _I, _D, _P, _P, _P]),
+    "d3pm_table_fingerprint": (_I, [_P, _L, _L, _L, _I, _I, _P, _P]),
     "d3pm_table_to_f32": (_I, [_P, _L, _L, _L, _I, _I, _P, _P]),
     "d3pm_q_probs": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _P]),
     "d3pm_q_sample": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _I, _U64, _U64, _P, _P, _P]),

@@ -25,6 +25,23 @@ int hip_fail(hipError_t e, const char* what);
     }                                                \
   } while (0)
 
+// A caller-supplied workspace that is too small: the usual D3PM_EINVAL, and the number of bytes that were needed is
+// noted for the calling thread (take_workspace_need() reads and clears it) -- entry points that bring a fixed
+// scratch buffer of their own tell "does not fit" from every other argument error by that, not by message text.
+void note_workspace_need(size_t bytes);
+size_t take_workspace_need();
+// Looks up the device address of the library's static scratch array on the current device if that has not
+// happened yet (a set-up call outside any stream capture; failures are ignored here and surface at first use).
+void warm_static_scratch();
+#define D3PM_CHECK_WORKSPACE(ptr, have, need)                                                        \
+  do {                                                                                               \
+    if (!((ptr) && (size_t)(have) >= (size_t)(need))) {                                              \
+      ::d3pm::note_workspace_need((size_t)(need));                                                   \
+      ::d3pm::set_error("workspace too small: %zu < %zu bytes", (size_t)(have), (size_t)(need));     \
+      return D3PM_EINVAL;                                                                            \
+    }                                                                                                \
+  } while (0)
+
 #define D3PM_LAUNCH_CHECK(what)                                  \
   do {                                                           \
     hipError_t e__ = hipGetLastError();                          \

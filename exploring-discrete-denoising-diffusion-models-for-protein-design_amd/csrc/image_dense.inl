@@ -671,8 +671,7 @@ static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0
                                int tb_, int B, long npos) {
   ImgArgs a = make_args(tb, x0, x0b, xt, xtb, t, tb_, B, npos, L::G);
   // matrix-core path: two workgroups per CU, two rounds of them over the chip (measured best of 512..4096)
-  static const int mfma_blocks = getenv("D3PM_DENSE_BLOCKS") ? atoi(getenv("D3PM_DENSE_BLOCKS")) : 1024;
-  const TokenGrid tg = token_grid(B, npos, DenseCfg<L, MFMA>::TM, MFMA ? mfma_blocks : 2048);
+  const TokenGrid tg = token_grid(B, npos, DenseCfg<L, MFMA>::TM, MFMA ? 1024 : 2048);
   a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
   return a;
 }
@@ -685,9 +684,8 @@ using MfmaLayout = Layout<16, 16, true, true>;
 
 template <class L, class F>
 static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
-  static const bool allow = !(getenv("D3PM_NO_MFMA") && atoi(getenv("D3PM_NO_MFMA")));
   if constexpr (L::VEC) {
-    if (allow && tb->K == 256) return f(MfmaLayout{}, std::true_type{});
+    if (tb->K == 256) return f(MfmaLayout{}, std::true_type{});
   }
   return f(L{}, std::false_type{});
 }
@@ -695,8 +693,7 @@ static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
 template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
 static int launch_tile(const d3pm_tables_f32* tb, const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   using C = DenseCfg<L, MFMA>;
-  static const size_t lds_pad = getenv("D3PM_DENSE_LDS_PAD") ? (size_t)atoi(getenv("D3PM_DENSE_LDS_PAD")) : 0;   // tuning aid: lowers occupancy
-  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * (MFMA ? 1 : (GRAD ? 3 : 2)) + lds_pad;
+  const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * (MFMA ? 1 : (GRAD ? 3 : 2));
   auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA>;
   if (sh > 48 * 1024) {
     hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -790,7 +787,7 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       constexpr bool MF = decltype(mf)::value;
       ImgArgs a = make_dense_args<L, MF>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
       DenseExtra e{};
       e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
       e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
@@ -836,7 +833,7 @@ static int dense_prior(const d3pm_tables_f32* tb, const void* x0, int tok_bytes,
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, nullptr, 8, B, npos, L::G);
     const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_dense_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_dense_prior");

@@ -726,7 +726,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int KC, bool GRAD, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, int stagger, int plog) {
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits) {
   using C = TplCfg<KC>;
   extern __shared__ __align__(16) char tpl_rows[];          // [waves][64][STRIDE]
   __shared__ float red[2 * MAX_WAVES];
@@ -764,7 +764,6 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
     }
   };
   unsigned base = pbeg + wave * 64;
-  for (int i = 0; i < wave * stagger; ++i) __builtin_amdgcn_s_sleep(1);
   // The timestep is requested first: loads retire in issue order, and the digest rows that depend on it should be
   // on their way while the logits rows arrive.
   const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
@@ -895,7 +894,7 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
           pr[j] = boe[j] * fast_rcp(f2);                    // boe_j / f2_j
           if constexpr (GRAD) E = fmaf(e[j], pr[j], E);
         }
-        if (plog && ((same_w >> q) & 1)) {
+        if ((same_w >> q) & 1) {
           // four classes of one weight w: sum_j w log2 pr_j = w log2 prod_j pr_j -- one logarithm.  Every pr_j lies in
           // [off / (off + diag - off), 1] with off >= eps = 1e-6, so the product stays above 1e-24, inside the
           // float32 range.  (The factor zr of every class is taken out of the sum: log2(zr) sum_j w_j below.  A term
@@ -1844,7 +1843,7 @@ static __device__ __align__(256) float g_loss_scratch[STATIC_SCRATCH_BYTES / siz
 
 // Device address of g_loss_scratch on the current device (the array's name is a host-side stand-in, not a device
 // address: kernels get this pointer).  Looked up once per device, with that device current.
-static int static_scratch(float** out) {
+static int static_scratch(float** out, hipStream_t stream, bool quiet = false) {
   constexpr int MAX_DEVICES = 64;
   static std::mutex mu;
   static float* ptrs[MAX_DEVICES] = {};
@@ -1854,6 +1853,16 @@ static int static_scratch(float** out) {
   D3PM_CHECK_ARG(dev >= 0 && dev < MAX_DEVICES, "device ordinal %d out of range", dev);
   std::lock_guard<std::mutex> lock(mu);
   if (!ptrs[dev]) {
+    if (!quiet) {
+      // the look-up is not a stream operation: under a capture it would fail, or end the capture, with an error
+      // that names neither
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      e = hipStreamIsCapturing(stream, &st);
+      if (e != hipSuccess) return hip_fail(e, "hipStreamIsCapturing");
+      D3PM_CHECK_ARG(st == hipStreamCaptureStatusNone,
+                     "d3pm_hybrid_loss_static: the first call on a device resolves the scratch array's address and "
+                     "cannot run under stream capture; call it (or d3pm_digest_f32) once on this device beforehand");
+    }
     float* p = nullptr;
     e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_loss_scratch));
     if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(g_loss_scratch)");
@@ -1864,20 +1873,29 @@ static int static_scratch(float** out) {
   return D3PM_OK;
 }
 
+namespace d3pm {
+void warm_static_scratch() {
+  float* p = nullptr;
+  (void)static_scratch(&p, nullptr, true);
+}
+}  // namespace d3pm
+
 extern "C" int d3pm_hybrid_loss_static(const d3pm_tables_f32* tb, const float* logits, long ld, const void* x0,
                                        int tok_bytes, const void* x_t, int xt_bytes, const void* t, int t_bytes, int B,
                                        long npos, int loss_type, float hybrid_coeff, float grad_scale,
                                        const float* grad_out, float* vb, float* ce, float* loss, float* dlogits,
                                        float* loss_mean, uint64_t* rng_counter, uint64_t rng_step, void* stream) {
   float* scratch = nullptr;
-  if (int rc = static_scratch(&scratch)) return rc;
+  if (int rc = static_scratch(&scratch, (hipStream_t)stream)) return rc;
+  (void)take_workspace_need();
   const int rc = d3pm_hybrid_loss(tb, logits, ld, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, loss_type,
                                   hybrid_coeff, grad_scale, grad_out, vb, ce, loss, dlogits, loss_mean, rng_counter,
                                   rng_step, scratch, STATIC_SCRATCH_BYTES, stream);
-  if (rc == D3PM_EINVAL && strstr(d3pm_last_error(), "workspace too small")) {
-    set_error("d3pm_hybrid_loss_static: B = %d x npos = %ld needs more partial sums than the %zu-byte static scratch "
-              "holds (8 bytes per workgroup); call d3pm_hybrid_loss with a workspace of "
-              "d3pm_hybrid_loss_workspace() bytes instead", B, npos, STATIC_SCRATCH_BYTES);
+  const size_t need = take_workspace_need();
+  if (rc == D3PM_EINVAL && need > STATIC_SCRATCH_BYTES) {
+    set_error("d3pm_hybrid_loss_static: B = %d x npos = %ld needs %zu bytes of partial sums, more than the %zu-byte "
+              "static scratch holds (8 bytes per workgroup); call d3pm_hybrid_loss with a workspace of "
+              "d3pm_hybrid_loss_workspace() bytes instead", B, npos, need, STATIC_SCRATCH_BYTES);
   }
   return rc;
 }
@@ -1890,9 +1908,8 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
   float* partials = (float*)workspace;
   const size_t partial_bytes = workspace_bytes;
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits));
-  static const int version = getenv("D3PM_LOSS_V") ? atoi(getenv("D3PM_LOSS_V")) : 3;
   const int K = tb->K;
-  if (version == 3 && vec && (K == 8 || K == 16 || K == 24 || K == 32)) {
+  if (vec && (K == 8 || K == 16 || K == 24 || K == 32)) {
     // one token per lane
     ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, 1);
     int block;
@@ -1903,9 +1920,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
     // per element against 256-thread workgroups: B = 320 11.9 / 9.8 us, 384 13.4 / 10.7, 448 12.3 / 15.0,
     // 512 13.9 / 14.2, 768 20.3 / 18.6, 2048 50.6 / 44.9 (0.70 / 0.79 of the HBM roofline: a 1024-thread workgroup
     // fills a CU alone and loads, computes and stores in lock step).
-    static const char* one_wg_env = getenv("D3PM_LOSS_ONE_WG_MAX");
-    static const int one_wg_max = one_wg_env ? atoi(one_wg_env) : 256;
-    const bool one_wg = B >= 192 && (B <= one_wg_max || (!one_wg_env && B >= 432 && B <= 512));
+    const bool one_wg = B >= 192 && (B <= 256 || (B >= 432 && B <= 512));
     if (one_wg) {
       const long want = ((npos + 63) / 64) * 64;
       block = (int)(want > 512 ? 512 : want);      // (1024 threads leave 128 registers a lane: spills)
@@ -1914,19 +1929,17 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
     } else {
       block = 256;
       // (large batches: one chunk per element as soon as that gives two workgroups per CU -- no second launch)
-      static const int big_target = getenv("D3PM_BIG_TARGET") ? atoi(getenv("D3PM_BIG_TARGET")) : 512;
-      static const int small_target = getenv("D3PM_SMALL_TARGET") ? atoi(getenv("D3PM_SMALL_TARGET")) : 512;   // (long rows: B = 8 x 32768 positions 24.1 -> 18.9 us against 1024)
-      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : small_target);
+      // (512 workgroups in all; long rows, B = 8 x 32768 positions: 24.1 -> 18.9 us against 1024)
+      const TokenGrid tg = token_grid(B, npos, block, 512);
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }
     if (a.chunks > 1) {
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-      D3PM_CHECK_ARG(partials && partial_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      D3PM_CHECK_WORKSPACE(partials, partial_bytes, need);
       o.part = partials;
     }
-    static const int pair = getenv("D3PM_LOSS_PAIR") ? atoi(getenv("D3PM_LOSS_PAIR")) : 1;   // 0: one token per lane
-    if (pair && K == 32 && a.chunks == 1 && one_wg) {
+    if (K == 32 && a.chunks == 1 && one_wg) {
       // two lanes per token: 32 tokens per wave, up to 16 waves per workgroup
       const long waves = (npos + 31) / 32;
       const int pblock = (int)(waves > 16 ? 16 : waves) * 64;
@@ -1956,10 +1969,8 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       }
-      static const int stagger = getenv("D3PM_STAGGER") ? atoi(getenv("D3PM_STAGGER")) : 0;
-      static const int plog = getenv("D3PM_LOSS_PLOG") ? atoi(getenv("D3PM_LOSS_PLOG")) : 1;   // 0: one logarithm per class
       hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale,
-                         grad_out, o, dlogits, stagger, plog);
+                         grad_out, o, dlogits);
       D3PM_LAUNCH_CHECK("k_hybrid_loss_tpl");
       return D3PM_OK;
     };
@@ -1992,7 +2003,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
     // directly; small batches are split over chunks and summed by k_loss_finalize.
     int block = BLOCK;
     if (B >= 192) {
-      static const int tpg = getenv("D3PM_TOKENS_PER_GROUP") ? atoi(getenv("D3PM_TOKENS_PER_GROUP")) : 4;
+      constexpr int tpg = 4;
       long want = ((npos + tpg - 1) / tpg) * L::G;       // lane groups make ~tpg trips each
       want = ((want + 63) / 64) * 64;
       const long cap = loss_max_threads<L>();
@@ -2007,7 +2018,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
     }
     if (a.chunks > 1) {
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-      D3PM_CHECK_ARG(partials && partial_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      D3PM_CHECK_WORKSPACE(partials, partial_bytes, need);
       o.part = partials;
     }
     const dim3 grid(B * a.chunks), blk(block);
@@ -2060,8 +2071,7 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
                           sample, probs, s);
   const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
                    (!probs || aligned16(probs));
-  static const bool allow_flat = !(getenv("D3PM_PSAMPLE_FLAT") && !atoi(getenv("D3PM_PSAMPLE_FLAT")));
-  if (allow_flat && noise_kind == D3PM_NOISE_PHILOX && !probs && vec && tb->K == 32 && npos >= 64 && B <= (1 << 20) &&
+  if (noise_kind == D3PM_NOISE_PHILOX && !probs && vec && tb->K == 32 && npos >= 64 && B <= (1 << 20) &&
       (long)B * npos * ld < 0x3fffffffL) {
     // the sampling loop's call: tokens of the whole batch as one row, 64 per wave
     ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, 1);
@@ -2072,8 +2082,7 @@ extern "C" int d3pm_p_sample(const d3pm_tables_f32* tb, const float* logits, lon
     D3PM_LAUNCH_CHECK("k_p_sample_flat");
     return D3PM_OK;
   }
-  static const bool allow_rows = !(getenv("D3PM_PSAMPLE_ROWS") && !atoi(getenv("D3PM_PSAMPLE_ROWS")));
-  if (allow_rows && noise_kind == D3PM_NOISE_PHILOX && !probs && vec && (tb->K == 64 || tb->K == 128 || tb->K == 256)) {
+  if (noise_kind == D3PM_NOISE_PHILOX && !probs && vec && (tb->K == 64 || tb->K == 128 || tb->K == 256)) {
     // the sampling loop's call at K = 64 / 128 / 256: a token on 8 or 16 lanes (8 or 16 classes a lane, interleaved
     // 16-byte pieces) instead of 16 / 32 / 64, so that the softmax reductions, the prefix scan of the draw and its
     // search stay inside one DPP row and a wave takes 4 or 8 tokens per pass
@@ -2120,7 +2129,7 @@ extern "C" int d3pm_prior_bpd(const d3pm_tables_f32* tb, const void* x0, int tok
     using L = decltype(lay);
     ImgArgs a = make_args(tb, x0, tok_bytes, nullptr, 8, nullptr, 8, B, npos, L::G);
     const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
-    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_prior<L>, dim3(B * a.chunks), dim3(BLOCK), 0, s, a, absorbing, part);
     D3PM_LAUNCH_CHECK("k_prior");

@@ -164,8 +164,7 @@ int dispatch_layout(int K, bool vec_ok, F&& f) {
 // small enough to afford it.
 template <class F>
 int dispatch_layout_wide(int K, bool vec_ok, F&& f) {
-  static const int lanes = getenv("D3PM_WIDE") ? atoi(getenv("D3PM_WIDE")) : 1;
-  if (vec_ok && lanes) {
+  if (vec_ok) {
     switch (K) {
       case 32: return f(Layout<4, 8, true>{});
       case 64: return f(Layout<8, 8, true>{});

@@ -1111,8 +1111,7 @@ extern "C" int d3pm_corrupt(const d3pm_tables_f64* tb, const int64_t* x0, const 
   if (int rc = check_prot(tb, B, npos)) return rc;
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(x0 && t && x_t, "null pointer");
-  static const bool allow_lane = !(getenv("D3PM_CORRUPT_OLD") && atoi(getenv("D3PM_CORRUPT_OLD")));
-  if (allow_lane && !expo && !probs && tb->K <= 64) {
+  if (!expo && !probs && tb->K <= 64) {
     ProtArgs a = make_prot(tb, x0, nullptr, t, B, npos, 1);
     hipLaunchKernelGGL(k_corrupt_lane, dim3(B * a.chunks), dim3(256), 0, (hipStream_t)stream, a, seed, offset, x_t);
     D3PM_LAUNCH_CHECK("k_corrupt_lane");
@@ -1151,8 +1150,7 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
   // training form (both D3PMLVBLoss and its MSA variant): one token per lane, float32 (K = 22 with rows of 22 or
   // 24 logits, the two alphabets of the reference's denoisers); every other shape, and forward-only evaluation,
   // on the float64 kernel
-  static const bool allow_tpl = !(getenv("D3PM_LVB_F64") && atoi(getenv("D3PM_LVB_F64")));
-  if (allow_tpl && dpred && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+  if (dpred && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
       ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
     int block;
@@ -1162,8 +1160,7 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
     // walking its chunk pass by pass with the next rows requested ahead (L = 512, one workgroup per element against
     // 256-thread workgroups: B = 320 12.5 / 11.4 us, 512 14.0 / 12.1, 768 23.9 / 18.2, 2048 60.8 / 40.6).  Smaller
     // batches: 256-thread chunks.
-    static const int lvb_one_wg_max = getenv("D3PM_LVB_ONE_WG_MAX") ? atoi(getenv("D3PM_LVB_ONE_WG_MAX")) : 256;
-    if (B >= 192 && B <= lvb_one_wg_max) {
+    if (B >= 192 && B <= 256) {
       const long want = ((npos + 63) / 64) * 64;
       block = (int)(want > 512 ? 512 : want);
       a.chunks = 1;
@@ -1171,16 +1168,15 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
     } else {
       block = 256;
       // (large batches: one chunk per element as soon as that gives two workgroups per CU -- no second launch)
-      static const int big_target = getenv("D3PM_BIG_TARGET") ? atoi(getenv("D3PM_BIG_TARGET")) : 512;
-      static const int small_target = getenv("D3PM_SMALL_TARGET") ? atoi(getenv("D3PM_SMALL_TARGET")) : 512;   // (long rows: B = 8 x 32768 positions 24.1 -> 18.9 us against 1024)
-      const TokenGrid tg = token_grid(B, npos, block, B > 256 ? big_target : small_target);
+      // (512 workgroups in all; long rows, B = 8 x 32768 positions: 24.1 -> 18.9 us against 1024)
+      const TokenGrid tg = token_grid(B, npos, block, 512);
       a.chunks = tg.chunks;
       a.chunk_pos = tg.chunk_pos;
     }
     double* part = (double*)workspace;
     if (a.chunks > 1) {
       const size_t need = (hyb ? 2 : 1) * (size_t)B * a.chunks * sizeof(double);
-      D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
     }
     auto go = [&](auto ldc, auto msac, auto hybc) -> int {
       constexpr int LDC = decltype(ldc)::value;
@@ -1214,7 +1210,7 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
     using L = decltype(lay);
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, L::G);
     const size_t need = (hyb ? 2 : 1) * (size_t)B * a.chunks * sizeof(double);
-    D3PM_CHECK_ARG(workspace && workspace_bytes >= need, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
     double* part = (double*)workspace;
     double* part_ce = part + (size_t)B * a.chunks;
     const dim3 grid(B * a.chunks), block(PBLOCK);
@@ -1260,16 +1256,13 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   if (B == 0 || npos == 0) return D3PM_OK;
   D3PM_CHECK_ARG(pred && x_t && t && out, "null pointer");
   D3PM_CHECK_ARG(npos * ld < 0x1fffffffL, "one batch element spans %ld predictions: more than 2^29", npos * ld);
-  static const bool allow_tpl = !(getenv("D3PM_REV_OLD") && atoi(getenv("D3PM_REV_OLD")));
-  static const bool allow_flat = !(getenv("D3PM_REV_FLAT") && !atoi(getenv("D3PM_REV_FLAT")));
-  if (allow_tpl && allow_flat && !expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+  if (!expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
       npos >= 64 && B <= (1 << 20) && (long)B * npos * ld < 0x3fffffffL) {
     // tokens of the whole batch as one row, 64 per wave
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, 1);
     const unsigned ntok = (unsigned)((long)B * npos);
     const unsigned waves = (ntok + 63) / 64;
-    static const int flat_block = getenv("D3PM_REV_FLAT_BLOCK") ? atoi(getenv("D3PM_REV_FLAT_BLOCK")) : 256;
-    const int block = (flat_block == 64 || flat_block == 128) ? flat_block : 256;
+    constexpr int block = 256;
     const unsigned wpb = block / 64;
     auto go = [&](auto ldc) -> int {
       constexpr int LDC = decltype(ldc)::value;
@@ -1282,7 +1275,7 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
     };
     return ld == 22 ? go(std::integral_constant<int, 22>{}) : go(std::integral_constant<int, 24>{});
   }
-  if (allow_tpl && !expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0) {
+  if (!expo && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0) {
     // one token per lane
     ProtArgs a = make_prot(tb, nullptr, x_t, t, B, npos, 1);
     int block;
@@ -1314,8 +1307,7 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
   }
   if (!expo && ld <= 32) {
     // few lanes per token: the draw is cheap per class, the cross-lane steps are what costs
-    static const int rev_blocks = getenv("D3PM_REV_BLOCKS") ? atoi(getenv("D3PM_REV_BLOCKS")) : 1024;
-    static const int rev_lanes = getenv("D3PM_REV_LANES") ? atoi(getenv("D3PM_REV_LANES")) : 4;
+    constexpr int rev_blocks = 1024;
     auto launch_blk = [&](auto lay, auto blk) {
       using L = decltype(lay);
       constexpr int BLK = decltype(blk)::value;
@@ -1338,7 +1330,6 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
     auto launch = [&](auto lay) {
       using L = decltype(lay);
       // workgroup size with the fewest idle token slots over a chunk (ties: the larger workgroup)
-      static const int force = getenv("D3PM_REV_BLOCK") ? atoi(getenv("D3PM_REV_BLOCK")) : 0;
       int best = 256;
       long best_slots = -1;
       for (int blk : {256, 192, 128}) {
@@ -1351,14 +1342,12 @@ extern "C" int d3pm_lvb_reverse_step(const d3pm_tables_f64* tb, const float* pre
         }
         if (best_slots < 0 || slots < best_slots) { best_slots = slots; best = blk; }
       }
-      if (force) best = force;
       if (best == 192) return launch_blk(lay, std::integral_constant<int, 192>{});
       if (best == 128) return launch_blk(lay, std::integral_constant<int, 128>{});
       return launch_blk(lay, std::integral_constant<int, 256>{});
     };
-    if (rev_lanes == 2) return ld <= 24 ? launch(Layout<2, 12, false>{}) : launch(Layout<2, 16, false>{});
-    if (rev_lanes == 4) return ld <= 24 ? launch(Layout<4, 6, false>{}) : launch(Layout<4, 8, false>{});
-    return ld <= 24 ? launch(Layout<8, 3, false>{}) : launch(Layout<8, 4, false>{});
+    // four lanes per token (two and eight measured slower)
+    return ld <= 24 ? launch(Layout<4, 6, false>{}) : launch(Layout<4, 8, false>{});
   }
   return dispatch_layout(tb->K, false, [&](auto lay) {
     using L = decltype(lay);

@@ -22,6 +22,14 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local size_t g_workspace_need = 0;
+void note_workspace_need(size_t bytes) { g_workspace_need = bytes; }
+size_t take_workspace_need() {
+  const size_t n = g_workspace_need;
+  g_workspace_need = 0;
+  return n;
+}
+
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return D3PM_EHIP;
@@ -165,6 +173,11 @@ __global__ __launch_bounds__(256) void k_digest(const double* __restrict__ table
     const int irep = (j == 0) ? 1 : 0;            // representative off-diagonal row of column j
     const double rep = m[(long)irep * sr + (long)j * sc];
     if (i == j) {
+      // a diagonal entry below the column's off-diagonal value also counts as a break: the one-uniform samplers
+      // take the diagonal's surplus over the off-diagonal value as a non-negative extra mass of that class.  (Below
+      // by more than rounding: where a cumulative product has mixed completely the two are equal up to the last
+      // bits of independent float64 dot products, and a surplus of -1e-6 of the class weight moves no draw.)
+      if (x < rep * (1.0 - 1e-6)) ++bad;
       if constexpr (F32) {
         const float d = (float)x;
         dg[0 * K + j] = d;
@@ -224,6 +237,32 @@ __global__ void k_cast_f32(const double* __restrict__ table, long st, long sr, l
   }
 }
 
+// 64-bit content fingerprint of a strided [T,K,K] float64 table: the sum, modulo 2^64, of every element's bit
+// pattern times an odd multiplier derived from its index (splitmix64 of the index).  Integer addition is
+// associative, so the order in which workgroups add their partial sums does not matter.
+__global__ __launch_bounds__(256) void k_fingerprint(const double* __restrict__ table, long st, long sr, long sc, int K,
+                                                     unsigned long long* __restrict__ out) {
+  const int t = blockIdx.x;
+  const double* m = table + (long)t * st;
+  unsigned long long acc = 0;
+  for (int e = threadIdx.x; e < K * K; e += blockDim.x) {
+    const int i = e / K, j = e - i * K;
+    unsigned long long z = (unsigned long long)t * (unsigned long long)(K * K) + e + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    acc += __builtin_bit_cast(unsigned long long, m[(long)i * sr + (long)j * sc]) * (z | 1ull);
+  }
+  __shared__ unsigned long long red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
 static int launch_chain(int K, int T, const double* mats, long st, long sr, long sc, double* out, hipStream_t s) {
   D3PM_CHECK_ARG(K >= 1 && K <= 1024, "cumulative product supports 1 <= K <= 1024, got %d", K);
   const int block = ((K + 63) / 64) * 64;
@@ -274,6 +313,7 @@ extern "C" int d3pm_digest_f32(const double* table, long st, long sr, long sc, i
                                int* violations, void* stream) {
   D3PM_CHECK_ARG(table && digest && violations, "null pointer");
   D3PM_CHECK_ARG(K >= 2 && T >= 1, "need K >= 2 and T >= 1");
+  warm_static_scratch();     // a set-up call, outside any capture: d3pm_hybrid_loss_static finds its array resolved
   hipLaunchKernelGGL(k_digest<float>, dim3(T), dim3(256), 0, (hipStream_t)stream, table, st, sr, sc, K, (double)eps,
                      digest, violations);
   D3PM_LAUNCH_CHECK("k_digest<float>");
@@ -287,6 +327,15 @@ extern "C" int d3pm_digest_f64(const double* table, long st, long sr, long sc, i
   hipLaunchKernelGGL(k_digest<double>, dim3(T), dim3(256), 0, (hipStream_t)stream, table, st, sr, sc, K, rtol, digest,
                      violations);
   D3PM_LAUNCH_CHECK("k_digest<double>");
+  return D3PM_OK;
+}
+
+extern "C" int d3pm_table_fingerprint(const double* table, long st, long sr, long sc, int T, int K, uint64_t* out,
+                                      void* stream) {
+  D3PM_CHECK_ARG(table && out && K >= 1 && T >= 1, "null pointer or empty table");
+  hipLaunchKernelGGL(k_fingerprint, dim3(T), dim3(256), 0, (hipStream_t)stream, table, st, sr, sc, K,
+                     (unsigned long long*)out);
+  D3PM_LAUNCH_CHECK("k_fingerprint");
   return D3PM_OK;
 }
 

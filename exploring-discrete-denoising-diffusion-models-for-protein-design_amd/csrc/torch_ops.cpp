@@ -444,6 +444,22 @@ std::tuple<Tensor, Tensor> digest_f64(const Tensor& table, double rtol) {
                            dg.data_ptr<double>(), viol.data_ptr<int>(), stream()));
   return {dg, viol};
 }
+// content fingerprints of several same-device float64 tables in one tensor (int64 [n]): the cache key of callers
+// that are handed fresh copies of their tables on every call (notebook cell-12)
+Tensor table_fingerprints(at::TensorList tables) {
+  TORCH_CHECK(tables.size() >= 1, "d3pm_mi355x: at least one table");
+  D3PM_GUARD(tables[0]);
+  Tensor out = at::zeros({(int64_t)tables.size()}, tables[0].options().dtype(at::kLong));
+  for (size_t i = 0; i < tables.size(); ++i) {
+    const Tensor& tb = tables[i];
+    need_table(tb, "table");
+    TORCH_CHECK(tb.device() == tables[0].device(), "d3pm_mi355x: tables on different devices");
+    check_rc(d3pm_table_fingerprint(f64(tb, "table"), tb.stride(0), tb.stride(1), tb.stride(2), (int)tb.size(0),
+                                    (int)tb.size(1), (uint64_t*)(out.data_ptr<int64_t>() + i), stream()));
+  }
+  return out;
+}
+
 // the float32 cast of _at / _at_onehot (:218, :242), done once, into a contiguous [T,K,K]
 Tensor table_to_f32(const Tensor& table) {
   D3PM_GUARD(table);
@@ -576,6 +592,7 @@ TORCH_LIBRARY(d3pm_mi355x, m) {
   m.def("digest_f32(Tensor table, float eps) -> (Tensor, Tensor)");
   m.def("digest_f64(Tensor table, float rtol) -> (Tensor, Tensor)");
   m.def("table_to_f32(Tensor table) -> Tensor");
+  m.def("table_fingerprints(Tensor[] tables) -> Tensor");
   m.def("lvb_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
         "float grad_scale, bool want_grad) -> (Tensor, Tensor)");
   m.def("lvb_hybrid_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
@@ -606,6 +623,7 @@ TORCH_LIBRARY_IMPL(d3pm_mi355x, CUDA, m) {
   m.impl("digest_f32", digest_f32);
   m.impl("digest_f64", digest_f64);
   m.impl("table_to_f32", table_to_f32);
+  m.impl("table_fingerprints", table_fingerprints);
   m.impl("lvb_loss", lvb_loss);
   m.impl("lvb_hybrid_loss", lvb_hybrid_loss);
   m.impl("lvb_reverse_step", lvb_reverse_step);

@@ -508,11 +508,12 @@ class DiscreteDiffusion:
         """First half of ``training_step``: one launch drawing the timesteps and the
         noisy tokens.  ``rng=(seed, counter)``: Philox stream offset = ``offset`` + the
         counter's value when the kernel runs.  It depends on nothing but ``x_start`` and
-        the counter.  Issue both halves on ONE stream: the counter is advanced by the
-        loss kernel, and a HIP graph with the corruption on a second captured stream
-        (fork / join inside the capture) left a hardware queue hung under the profiler on
-        the test machine, so no multi-stream use of the two halves is supported.
-        Returns the dict ``loss_step`` takes."""
+        the counter.  Both halves go on ONE stream: this launch reads the counter and
+        the loss launch advances it, and nothing but stream order stands between that
+        read and that write, so ``loss_step`` refuses to run on another stream than this
+        call's (to overlap the next batch's corruption with a loss, use
+        ``loss_step(prefetch=...)``: one launch does both).  Returns the dict
+        ``loss_step`` takes."""
         if self.loss_type not in _lib.LOSS:
             raise NotImplementedError(self.loss_type)
         if self.model_prediction != "x_start":
@@ -531,7 +532,8 @@ class DiscreteDiffusion:
             seed, off = _philox_ticket(dev)
         mean = torch.empty((), dtype=torch.float32, device=dev) if device_mean else None   # zeroed by this launch
         t, x_t = ops.q_sample_draw_t(*tb.op_args(), x0, i64(seed), i64(off), counter, mean)
-        return {"t": t, "x_t": x_t, "mean": mean, "counter": counter, "seed": seed}
+        return {"t": t, "x_t": x_t, "mean": mean, "counter": counter, "seed": seed,
+                "stream": torch.cuda.current_stream(dev).cuda_stream}
 
     def loss_step(self, model_fn, *, x_start, corrupted, backward=True, advance=4, prefetch=None):
         """Second half of ``training_step``: the denoiser, then one launch for the
@@ -550,6 +552,10 @@ class DiscreteDiffusion:
         B, npos = self._dims(x0)
         dev = x0.device
         t, x_t, mean, counter = corrupted["t"], corrupted["x_t"], corrupted["mean"], corrupted["counter"]
+        if corrupted.get("stream", None) is not None and \
+                torch.cuda.current_stream(dev).cuda_stream != corrupted["stream"]:
+            raise RuntimeError("loss_step must be issued on the stream corrupt_step ran on (the two launches share a "
+                               "Philox counter ordered by one stream only); for overlap use loss_step(prefetch=...)")
         pred = self._denoiser_logits(model_fn, x_t, t)
         assert pred.shape == x0.shape + (tb.K,), pred.shape
         lg = pred.detach().contiguous()
@@ -574,7 +580,8 @@ class DiscreteDiffusion:
                 seed, off = _philox_ticket(dev)
             losses, dl, nt, nxt_tokens = ops.hybrid_loss_then_q_sample(*tb.op_args(), lg, x0, x_t, t, lt, lam, scale,
                                                                        want_grad, nx0, i64(seed), i64(off), counter)
-            nxt = {"t": nt, "x_t": nxt_tokens, "mean": None, "counter": counter, "seed": seed}
+            nxt = {"t": nt, "x_t": nxt_tokens, "mean": None, "counter": counter, "seed": seed,
+                   "stream": torch.cuda.current_stream(dev).cuda_stream}
         if want_grad:
             holder = [dl.view(pred.shape) if dl.dtype == pred.dtype else dl.view(pred.shape).to(pred.dtype)]
             del dl

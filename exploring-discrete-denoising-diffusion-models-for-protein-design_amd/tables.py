@@ -103,22 +103,63 @@ class ProteinTables:
         return (self.qbar_digest, self.qone_digest, self.K, self.T)
 
 
-_protein_cache: Dict[tuple, ProteinTables] = {}
+# Two keys lead to a ProteinTables: the identity of the caller's tensors (storage pointer + version: no device work
+# at all when the same tensors come back, the collaters' own `self.Q` for instance) and, when that misses, the
+# tables' content (a 64-bit fingerprint per table: one short launch each and one host read).  The reference's
+# training loop uploads Q and Q_bar anew on every step (Protein Generation Notebook.ipynb cell-12:
+# `Q = Q.to(device)`), so the loss sees fresh pointers with known content step after step; the content key turns
+# that into a hit instead of two digest builds and their structure check.
+_by_identity: Dict[tuple, ProteinTables] = {}
+_by_content: Dict[tuple, ProteinTables] = {}
+_MAX_ENTRIES = 8
+builds = 0          # ProteinTables constructed by protein_tables() so far (read by the tests)
+
+
+def _host_fingerprint(x: torch.Tensor) -> int:
+    """The fingerprint of d3pm_table_fingerprint evaluated on the host (numpy, modulo 2^64): a table has one content
+    key wherever it lives."""
+    import numpy as np
+    bits = x.detach().cpu().to(torch.float64).contiguous().numpy().reshape(-1).view(np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.arange(bits.size, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        f = int((bits * (z | np.uint64(1))).sum(dtype=np.uint64))
+    return f - (1 << 64) if f >= (1 << 63) else f          # as the int64 the device tensor holds
+
+
+def _content_key(Q: torch.Tensor, Q_bar: torch.Tensor, dev: torch.device) -> tuple:
+    if Q.is_cuda and Q_bar.is_cuda and Q.dtype == Q_bar.dtype == torch.float64 and Q.device == Q_bar.device:
+        fq, fb = ops.table_fingerprints([Q, Q_bar]).tolist()       # two short launches, one host read
+    else:
+        fq, fb = _host_fingerprint(Q), _host_fingerprint(Q_bar)     # hashed where they are, before any upload
+    return (fq, fb, tuple(Q.shape), str(dev))
 
 
 def protein_tables(Q: torch.Tensor, Q_bar: torch.Tensor, device=None) -> ProteinTables:
     """Cached ProteinTables for the (Q, Q_bar) pair a caller passes on every
     call (losses.py:48, generate.py:8).  CPU tensors are uploaded once."""
-    key = (Q.data_ptr(), Q._version, Q_bar.data_ptr(), Q_bar._version, tuple(Q.shape), str(device or Q.device))
-    hit = _protein_cache.get(key)
+    global builds
+    dev = torch.device(device) if device is not None else Q.device
+    ident = (Q.data_ptr(), Q._version, Q_bar.data_ptr(), Q_bar._version, tuple(Q.shape), str(dev))
+    hit = _by_identity.get(ident)
     if hit is not None:
         return hit
-    dev = torch.device(device) if device is not None else Q.device
     if dev.type != "cuda":
         raise RuntimeError("protein-style kernels need a HIP device; there is no CPU path in this package")
+    assert Q.dim() == 3 and Q.shape == Q_bar.shape and Q.shape[1] == Q.shape[2], (Q.shape, Q_bar.shape)
+    content = _content_key(Q, Q_bar, dev)
+    tb = _by_content.get(content)
+    if tb is not None:
+        # a fresh copy of known tables: nothing is kept of it (its pointer may be recycled for other content)
+        return tb
     tb = ProteinTables(Q.to(dev), Q_bar.to(dev))
-    tb._src = (Q, Q_bar)           # keep the key's storage alive so data_ptr cannot be recycled
-    if len(_protein_cache) > 8:
-        _protein_cache.clear()
-    _protein_cache[key] = tb
+    builds += 1
+    tb._src = (Q, Q_bar)           # keep the identity key's storage alive so its data_ptr cannot be recycled
+    for cache in (_by_identity, _by_content):
+        while len(cache) >= _MAX_ENTRIES:
+            cache.pop(next(iter(cache)))           # oldest entry first
+    _by_identity[ident] = tb
+    _by_content[content] = tb
     return tb

@@ -107,6 +107,17 @@ int d3pm_digest_f32(const double* table, long st, long sr, long sc, int T, int K
 int d3pm_digest_f64(const double* table, long st, long sr, long sc, int T, int K, double rtol,
                     double* digest, int* violations, void* stream);
 
+/* 64-bit content fingerprint of a strided [T,K,K] float64 table, added into
+ * *out (device, zeroed by the caller): sum over all elements of bit pattern x
+ * index-derived odd multiplier, modulo 2^64.  The reference's protein drivers
+ * hand Q and Q_bar to every call and upload them anew every step
+ * (Protein Generation Notebook.ipynb cell-12: Q.to(device), Q_bar.to(device);
+ * losses.py:48, generate.py:8 take them as arguments): a caller that caches
+ * digests per table keys them on this, so that a fresh copy of known tables
+ * costs one short launch instead of two digest builds. */
+int d3pm_table_fingerprint(const double* table, long st, long sr, long sc, int T, int K, uint64_t* out,
+                           void* stream);
+
 /* float64 -> float32 copy of a strided [T,K,K] table into a contiguous one
  * (the `a.to(dtype=float32)` of _at/_at_onehot, :218,:242, done once). */
 int d3pm_table_to_f32(const double* table, long st, long sr, long sc, int T, int K,

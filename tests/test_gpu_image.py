@@ -475,7 +475,7 @@ def test_graphed_bpd_sweep(pkg):
     assert r2["vbterms"].shape == (B, T) and torch.isfinite(r2["total"]).all()
 
 
-@pytest.mark.parametrize("kind,bits", [("gaussian", 8), ("gaussian", 6), ("uniform", 5)])
+@pytest.mark.parametrize("kind,bits", [("gaussian", 8), ("gaussian", 6), ("uniform", 5), ("absorbing", 5)])
 def test_p_sample_device_noise_distribution(pkg, kind, bits):
     """p_sample with noise drawn on the device (one uniform per token, inverse CDF
     over the posterior on the dense path): class frequencies over many identical
@@ -489,6 +489,8 @@ def test_p_sample_device_noise_distribution(pkg, kind, bits):
     row = (2.0 * torch.randn(K, generator=gen)).to(DEV)
     logits = row.expand(B, L, 1, 1, K).contiguous()
     x_t = torch.full((B, L, 1, 1), K // 3, device=DEV)
+    if kind == "absorbing":
+        x_t[2:] = K // 2          # the mask class, early and late timesteps: the one-uniform draw's extra mass on x_t
     t = torch.tensor([1, 2, 7, 20, 33, 49, 10, 5], dtype=torch.int32, device=DEV)
     torch.manual_seed(123)
     s, _ = d.p_sample(lambda x, tt: logits, x=x_t, t=t)
@@ -1087,3 +1089,60 @@ def test_operators_reject_mis_shaped_calls(pkg):
         with pytest.raises((ValueError, RuntimeError)):
             call()
             pytest.fail(f"mis-shaped call {i} was accepted")
+
+
+
+def test_tables_with_a_diagonal_below_the_off_diagonal_are_not_structured(pkg):
+    """The one-uniform samplers read a column's diagonal surplus over its off-diagonal value as a non-negative extra
+    mass, so a column-structured table whose diagonal is SMALLER than the off-diagonal value must not take the O(K)
+    path: the digest counts it as a break and the dense kernels serve it (p_sample frequencies against the
+    posterior)."""
+    from d3pm_amd.tables import ImageTables
+    K, T = 8, 6
+    off = torch.full((T, 1, K), 0.13, dtype=torch.float64)
+    Q = off.expand(T, K, K).clone()
+    idx = torch.arange(K)
+    Q[:, idx, idx] = 1.0 - 0.13 * (K - 1)                   # 0.09 < 0.13: rows still sum to one
+    bars = [Q[0]]
+    for i in range(1, T):
+        bars.append(bars[-1] @ Q[i])
+    Qbar = torch.stack(bars)
+    tb = ImageTables(Qbar.to(DEV), Q.to(DEV))
+    assert tb.violations[1] > 0 and not tb.structured
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type="uniform", num_bits=3,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    d.q_mats, d.transpose_q_onestep_mats = Qbar.to(DEV), Q.to(DEV).permute(0, 2, 1)
+    assert not d.tables().structured
+    B, L = 4, 20000
+    row = torch.tensor([0.3, -1.0, 2.0, 0.0, 1.0, -0.5, 0.7, 0.2], device=DEV)
+    logits = row.expand(B, L, 1, 1, K).contiguous()
+    x_t = torch.full((B, L, 1, 1), 2, device=DEV)
+    t = torch.tensor([1, 2, 4, 5], dtype=torch.int32, device=DEV)
+    torch.manual_seed(3)
+    s, _ = d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False)
+    post = d.q_posterior_logits(logits[:, :1], x_t[:, :1], t, x_start_logits=True)
+    P = torch.softmax(post.double(), -1).reshape(B, K).cpu().numpy()
+    for b in range(B):
+        freq = torch.bincount(s[b].flatten().cpu(), minlength=K).numpy() / L
+        assert (np.abs(freq - P[b]) < 5 * np.sqrt(P[b] * (1 - P[b]) / L) + 2e-4).all(), (b, freq, P[b])
+
+
+def test_training_step_halves_refuse_two_streams(pkg):
+    """corrupt_step and loss_step share a Philox counter that the loss launch advances: issued on two streams the
+    read and the write are unordered, so the second half refuses a stream other than the first half's."""
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, 20, "jsd"), transition_mat_type="uniform", num_bits=5,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    x0 = torch.randint(0, 32, (4, 70, 1, 1), device=DEV)
+    logits = torch.randn(4, 70, 1, 1, 32, device=DEV, requires_grad=True)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    c = d.corrupt_step(x_start=x0, rng=(7, counter))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="one stream"):
+            d.loss_step(lambda x, tt: logits, x_start=x0, corrupted=c)
+    torch.cuda.current_stream().wait_stream(side)
+    out = d.loss_step(lambda x, tt: logits, x_start=x0, corrupted=c)            # the stream of the first half: fine
+    assert torch.isfinite(out["losses"]).all() and int(counter.item()) == 4

@@ -359,6 +359,32 @@ def test_lvb_loss_without_q(pkg, tables500, want_grad):
     np.testing.assert_allclose(per[1:5], full.detach().cpu().numpy()[1:5], rtol=1e-12 if not want_grad else 1e-5)
 
 
+def test_protein_tables_hit_on_fresh_uploads(pkg):
+    """The reference's loop uploads Q and Q_bar anew on every step (notebook cell-12: Q.to(device)) and hands the
+    copies to the loss: fresh pointers, known content.  The digests are built once; another table builds again."""
+    from d3pm_amd import tables as tbl
+    tok = pkg.Tokenizer()
+    Qb, Qt = tok.q_uniform_schedule(num_steps=37, schedule="linear", device=DEV)
+    Qb_c, Qt_c = Qb.cpu(), Qt.cpu()
+    before = tbl.builds
+    seen = []
+    for _ in range(3):
+        seen.append(tbl.protein_tables(Qt_c.to(DEV), Qb_c.to(DEV)))           # fresh device copies, step after step
+    assert tbl.builds == before + 1 and seen[0] is seen[1] is seen[2]
+    assert tbl.protein_tables(Qt_c, Qb_c, device=DEV) is seen[0]                # the host tensors themselves
+    assert tbl.protein_tables(Qt_c.clone(), Qb_c.clone(), device=DEV) is seen[0] and tbl.builds == before + 1
+    other = Qb_c.clone()
+    other[5] = Qb_c[6]
+    assert tbl.protein_tables(Qt_c.to(DEV), other.to(DEV)) is not seen[0] and tbl.builds == before + 2
+    # through the loss module, as the notebook calls it
+    x0 = torch.randint(0, 22, (4, 50), device=DEV)
+    ts = torch.tensor([1, 5, 20, 36], device=DEV)
+    pred = torch.randn(4, 50, 22, device=DEV, requires_grad=True)
+    lf = pkg.D3PMLVBLoss(tmax=37, tokenizer=tok)
+    vals = [float(lf(None, None, pred, x0, None, ts, Qt_c.to(DEV), Qb_c.to(DEV), src=x0).detach()) for _ in range(2)]
+    assert vals[0] == vals[1] and tbl.builds == before + 2
+
+
 def test_generate_replay_golden(pkg):
     g = golden("protein_generate")
     tok = pkg.Tokenizer()

@@ -76,3 +76,44 @@ def test_static_scratch_rejects_oversize():
     torch.cuda.synchronize()
     assert rc == EINVAL and b"static scratch" in lib.d3pm_last_error()
     assert (loss == -7.0).all()
+
+
+def test_static_scratch_under_graph_capture():
+    """Warm (the scratch array's address is resolved at set-up), then capture a HIP graph that calls the entry point
+    with a chunked launch (partial sums in the scratch), replay it twice on fresh logits, and compare every output
+    with d3pm_hybrid_loss on the same inputs: the captured call allocated nothing and reads no stale state."""
+    import d3pm_amd
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
+    dev = torch.device("cuda:0")
+    d = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(0.0, 0.0, 50, "jsd"), transition_mat_type="uniform",
+                                   num_bits=5, transition_bands=None, model_prediction="x_start", model_output="logits",
+                                   loss_type="hybrid", hybrid_coeff=0.01, device=dev)
+    tb = d.tables()                          # d3pm_digest_f32 has resolved the array on this device
+    B, npos, K = 8, 300, 32
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randint(0, K, (B, npos), generator=g).to(dev)
+    t = torch.randint(1, 50, (B,), generator=g, dtype=torch.int32).to(dev)
+    xt = d.q_sample(x0, t, torch.rand(B, npos, K, generator=g).to(dev))
+    lg = torch.randn(B, npos, K, generator=g).to(dev)
+    loss, dl = torch.empty(B, device=dev), torch.empty_like(lg)
+
+    def call(stream):
+        check(lib.d3pm_hybrid_loss_static(tb.desc(), ptr(lg), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, npos,
+                                          LOSS["hybrid"], 0.01, 0.125, None, None, None, ptr(loss), ptr(dl), None, None,
+                                          0, stream))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(stream_ptr())
+    for seed in (5, 6):
+        lg.copy_(torch.randn(B, npos, K, generator=torch.Generator().manual_seed(seed)).to(dev))
+        loss.fill_(float("nan")); dl.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        want_loss, want_dl = torch.empty(B, device=dev), torch.empty_like(lg)
+        wsb = lib.d3pm_hybrid_loss_workspace(B, npos, K)
+        ws = torch.empty(max(wsb // 4, 1), device=dev)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, npos, LOSS["hybrid"], 0.01,
+                                   0.125, None, None, None, ptr(want_loss), ptr(want_dl), None, None, 0, ptr(ws), wsb,
+                                   stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(loss, want_loss) and torch.equal(dl, want_dl)

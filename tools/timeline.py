@@ -69,12 +69,9 @@ buf = np.zeros((256, 16, 9), dtype=np.uint64)
 assert raw.d3pm_debug_timeline(buf.ctypes.data_as(C.c_void_p)) == 0
 tl = buf[:B].astype(np.int64)
 SHADER = "SHADERCLK" in os.environ.get("D3PM_LIB", "")   # per-wave shader-clock ticks instead of global microseconds
-names = ["start", "t loaded", "digest rows arrived", "after barrier", "loop entry", "first row + specials arrived",
-         "first token pass done", "loop exit", "kernel end"]
-if os.environ.get("D3PM_LOSS_V", "3") == "3":       # the token-per-lane kernel
-    names = ["start", "t loaded", "rows arrived, staged in LDS", "phase A done", "tables staged",
-             "phase B arithmetic done", "gradient rows in LDS, patched", "next batch drawn (next mode)",
-             "global stores issued"]
+names = ["start", "t loaded", "rows arrived, staged in LDS", "phase A done", "tables staged",
+         "phase B arithmetic done", "gradient rows in LDS, patched", "next batch drawn (next mode)",
+         "global stores issued"]
 nw = int((tl[0, :, 0] != 0).sum())
 t0 = tl[:, :nw, 0].min()
 print(f"{nw} waves per workgroup; median over workgroups, microseconds from the earliest start, one column per wave")
