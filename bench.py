@@ -123,8 +123,8 @@ def _cpu_model() -> str:
 
 
 def _median_time(step, budget_s: float, warm: int = 3, blocks: int = 10):
-    """3 untimed calls, then the median over 10 timed blocks; a block repeats the call so that the ten blocks
-    together take about `budget_s`."""
+    """`warm` untimed calls, then the median over `blocks` timed blocks; a block repeats the call so that the
+    blocks together take about `budget_s`."""
     for _ in range(warm):
         step()
     t0 = time.perf_counter()
@@ -141,7 +141,7 @@ def _median_time(step, budget_s: float, warm: int = 3, blocks: int = 10):
     return 0.5 * (times[blocks // 2 - 1] + times[blocks // 2]), per_block * blocks
 
 
-def cpu_baselines(budget_s: float = 10.0):
+def cpu_baselines(budget_s: float = 10.0, image_tables=None):
     """The CPU oracle (a restatement of the reference's eager PyTorch path: float64 tables cast per call, every
     [N,K] intermediate materialised, per-sequence Python loops in the protein style, autograd backward) timed on
     this host's cores: the headline step, one protein-style loss step, one reverse-sampling step."""
@@ -201,7 +201,30 @@ def cpu_baselines(budget_s: float = 10.0):
            "sample": f"{n_r} reverse steps (posterior marginal + multinomial draw, frozen logits) on a {BR}-sequence "
                      f"slice (L={SEQ_LEN}, K={K_PROT}), median {med_r * 1e3:.1f} ms per step, extrapolated to the "
                      f"{T_PROT - 1} steps of a full run; {host}"}
-    return head, lvb, rev
+    # image configuration (K=256, T=1000, Gaussian): the oracle's training step on an 8-image slice of the 128-image
+    # batch.  The [T,K,K] float64 tables are the ones the GPU built (the reference's own build is 21.8 s of host
+    # time and is not part of a step); the step casts them whole to float32 per gather, as the reference does.
+    img = None
+    if image_tables is not None:
+        q_mats, qT, betas_i = image_tables
+        pi = im.Process(betas=betas_i, kind="gaussian", K=256, bands=None, q_mats=q_mats, qT_onestep=qT,
+                        hybrid_coeff=LAMBDA, loss_type="hybrid")
+        BI = 8
+        x0i = torch.randint(0, 256, (BI, 32, 32, 1), generator=g)
+        lgi = torch.randn(BI, 32, 32, 1, 256, generator=g, requires_grad=True)
+
+        def img_step():
+            noise = torch.rand(BI, 32, 32, 1, 256)
+            t = torch.randint(0, 1000, (BI,), dtype=torch.int32)
+            loss, _ = im.training_step(pi, lambda x, tt: lgi, x0i, t, noise)
+            lgi.grad = None
+            loss.mean().backward()
+
+        med_i, n_i = _median_time(img_step, budget_s, warm=1, blocks=4)
+        img = {"value": BI * 1024 / med_i, "unit": "tokens/s", "cores": cores, "kind": "port",
+               "sample": f"{n_i} training steps (q_sample + hybrid loss fwd+bwd) on an {BI}-image slice of the batch "
+                         f"(32x32x1, K=256, T=1000, Gaussian Q), median {med_i * 1e3:.0f} ms per step; {host}"}
+    return head, lvb, rev, img
 
 
 # ------------------------------------------------------------------ one rank
@@ -626,6 +649,7 @@ def worker(args):
     # the matrix cores, fused loss fwd+bwd; priced against the dense float32 MFMA peak
     progress("image K=256")
     dense = None
+    image_tables_cpu = None
     if rank == 0 and not args.no_secondary:
         KI, TI, BI, LI = 256, 1000, 128, 1024
         di = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(1e-4, 0.02, TI, "linear"),
@@ -652,7 +676,29 @@ def worker(args):
                  "kernel_ms": dms, "tokens_per_s": BI * LI / (dms * 1e-3),
                  "roofline": {"bound": "mfma", "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
                               "flops_per_token": 4 * KI * KI, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}}
-        del di, tbi, lgi, dli
+        if not args.no_cpu_baseline and world == 1:
+            image_tables_cpu = (di.q_mats.cpu(), di.transpose_q_onestep_mats.cpu(), di.betas.cpu())
+        # three channels (the CIFAR shape of the reference's notebook): B=128 32x32x3, 3072 positions per image
+        del lgi, dli
+        L3 = 3072
+        x03 = torch.randint(0, KI, (BI, 32, 32, 3), device=dev)
+        xt3 = di.q_sample(x03, ti)
+        lg3 = torch.randn(BI, 32, 32, 3, KI, device=dev)
+        dl3 = torch.empty_like(lg3)
+        wsb3 = lib.d3pm_hybrid_loss_workspace(BI, L3, KI)
+        ws3 = torch.empty(max(wsb3 // 4, 1), device=dev)
+
+        def dense_c3():
+            check(lib.d3pm_hybrid_loss(tbi.desc(), ptr(lg3), KI, ptr(x03), 8, ptr(xt3), 8, ptr(ti), 4, BI, L3,
+                                       LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dl3), None, None, 0,
+                                       ptr(ws3), wsb3, sp))
+        d3ms = event_ms(dense_c3, 40, warm=8)
+        tfl3 = 4.0 * KI * KI * BI * L3 / (d3ms * 1e-3) / 1e12
+        dense["three_channels"] = {"workload": "the same with B=128 32x32x3 (393 216 positions per launch)",
+                                   "kernel_ms": d3ms, "tokens_per_s": BI * L3 / (d3ms * 1e-3),
+                                   "roofline": {"bound": "mfma", "achieved": tfl3, "peak": 157.3, "unit": "TFLOP/s",
+                                                "frac": tfl3 / 157.3}}
+        del di, tbi, lg3, dl3
 
     # ---- secondary: the protein-style training loss (D3PMLVBLoss forward + gradient) and the batched forward
     # corruption of the collaters, B=256 L=512 K=22 n_tokens=24, through the C ABI
@@ -807,12 +853,14 @@ def worker(args):
             "large_batch": large,
         }
         if world == 1 and not args.no_cpu_baseline:
-            head, lvb_cpu, rev_cpu = cpu_baselines()
+            head, lvb_cpu, rev_cpu, img_cpu = cpu_baselines(image_tables=image_tables_cpu)
             out["cpu_baseline"] = head
             if lvb is not None:
                 lvb["cpu_baseline"] = lvb_cpu
             if reverse is not None:
                 reverse["cpu_baseline"] = rev_cpu
+            if dense is not None and img_cpu is not None:
+                dense["cpu_baseline"] = img_cpu
         print(json.dumps(out), flush=True)
     if use_pg:
         dist.barrier()

@@ -29,7 +29,8 @@ class TablesF32(C.Structure):
 
 
 class TablesF64(C.Structure):
-    _fields_ = [("K", C.c_int), ("T", C.c_int), ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p)]
+    _fields_ = [("K", C.c_int), ("T", C.c_int), ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p),
+                ("lvb_digest", C.c_void_p)]
 
 
 _P, _I, _L, _F, _D, _U64, _SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint64, C.c_size_t
@@ -64,6 +65,8 @@ SIGNATURES = {
     "d3pm_logistic_logits": (_I, [_P, _P, _P, _L, _I, _F, _P, _P]),
     "d3pm_logistic_logits_backward": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "d3pm_corrupt": (_I, [_T64, _P, _P, _I, _L, _P, _U64, _U64, _P, _P, _P]),
+    "d3pm_lvb_digest_f32_size": (_SZ, [_I]),
+    "d3pm_lvb_digest_f32": (_I, [_T64, _P, _P]),
     "d3pm_lvb_loss_workspace": (_SZ, [_I, _L, _I]),
     "d3pm_lvb_loss": (_I, [_T64, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _D, _P, _P, _P, _SZ, _P]),
     "d3pm_lvb_hybrid_loss": (_I, [_T64, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _D, _D, _P, _P, _P, _P, _SZ, _P]),

@@ -378,24 +378,77 @@ __device__ __forceinline__ float log2_1p(float d) {
   return fmaf(d - (w - 1.0f), 1.44269504088896340736f, __builtin_amdgcn_logf(w));
 }
 
+// ------------------------------------------------------------------ per-timestep constants of the float32 loss
+// What k_lvb_loss_tpl needs of the tables for a loss at timestep t, as float32 rows of 32 (d3pm_lvb_digest_f32):
+//   row 0 / 1: a_diag / a_off by x_t (column x_t of Q_t)          row 2: mo_j (off-diagonal of Qbar_{t-1} by column)
+//   row 3 / 4: Qbar_t[x0, x_t] for x0 == x_t / x0 != x_t by x_t   row 5 / 6: rho for x0 == x_t / x0 != x_t (MSA variant)
+//   row 7 / 8: log rho likewise                                   row 9: mdo = diag - off of Qbar_{t-1}, sum_j mo_j
+// Formed once per table in float64 (log rho as a difference of the float64 digests' logarithms: rho is close to one
+// at late timesteps), so that the loss kernel's set-up is a handful of scalar loads and one 32-lane copy into LDS.
+constexpr int LVB_ROWS = 10;
+__global__ __launch_bounds__(64) void k_lvb_digest32(d3pm_tables_f64 tb, float* __restrict__ out) {
+  const int K = tb.K, t = blockIdx.x, lane = threadIdx.x;
+  const int tm = max(0, min(t - 1, tb.T - 1)), tq = min(t, tb.T - 1);
+  float* o = out + (size_t)t * LVB_ROWS * 32;
+  const bool ok = lane < K;
+  const double vd64 = ok ? dgd(tb.qbar_digest, tm, 0, K)[lane] : 0.0, vo64 = ok ? dgd(tb.qbar_digest, tm, 1, K)[lane] : 0.0;
+  const double dd = ok ? dgd(tb.qbar_digest, tq, 0, K)[lane] : 0.0, dof = ok ? dgd(tb.qbar_digest, tq, 1, K)[lane] : 0.0;
+  const float vd = (float)vd64, vo = (float)vo64;
+  const float sum_mo = wave_sum(vo);
+  const float mdo = lane_broadcast(vd - vo, 0);
+  if (lane < 32) {
+    o[0 * 32 + lane] = ok ? (float)dgd(tb.qone_digest, tq, 0, K)[lane] : 0.0f;
+    o[1 * 32 + lane] = ok ? (float)dgd(tb.qone_digest, tq, 1, K)[lane] : 0.0f;
+    o[2 * 32 + lane] = vo;
+    o[3 * 32 + lane] = (float)dd;
+    o[4 * 32 + lane] = (float)dof;
+    // rho = Qbar_t[x0, x_t] / Qbar_{t-1}[x0, x_t]; a pair that Qbar_{t-1} gives no weight never occurs (x_t was
+    // drawn from it), its rho is left at zero
+    o[5 * 32 + lane] = vd64 > 0.0 ? (float)(dd / vd64) : 0.0f;
+    o[6 * 32 + lane] = vo64 > 0.0 ? (float)(dof / vo64) : 0.0f;
+    o[7 * 32 + lane] = (ok && vd64 > 0.0) ? (float)(dgd(tb.qbar_digest, tq, 2, K)[lane] - dgd(tb.qbar_digest, tm, 2, K)[lane]) : 0.0f;
+    o[8 * 32 + lane] = (ok && vo64 > 0.0) ? (float)(dgd(tb.qbar_digest, tq, 3, K)[lane] - dgd(tb.qbar_digest, tm, 3, K)[lane]) : 0.0f;
+    o[9 * 32 + lane] = lane == 0 ? mdo : (lane == 1 ? sum_mo : 0.0f);
+  }
+}
+
 // HYB: the driver's cross-entropy term in the same pass (Protein Generation Notebook cell-12, loss = (lvb + lambda *
 // CrossEntropyLoss(outputs, tgt)) * n_tokens): -log_softmax(z)[x0] over ALL LD logits for every token whatever its
-// element's timestep, summed per sequence into ce_seq; its gradient ce_scale / npos * (softmax(z) - e_x0) rides in
-// the coefficients of the gradient's last loop (softmax_j = e_j f / S_all: one more term on e_j), so a class costs
-// no further operation.  The softmax of the KL branch runs over the first K logits with their own maximum; the
-// LD - K further logits enter through m_all = max(m, z_K..) and f = 2^(m - m_all), every exponent <= 0.
+// element's timestep, summed per sequence into ce_seq; its gradient ces * (softmax(z) - e_x0) rides in the
+// coefficients of the gradient's last loop (softmax_j = e_j f / S_all: one more term on e_j), so a class costs no
+// further operation.  The softmax of the KL branch runs over the first K logits with their own maximum; the LD - K
+// further logits enter through m_all = max(m, z_K..) and f = 2^(m - m_all), every exponent <= 0.
+//
+// The class x0 in the KL branch.  Its logit is read from the lane's LDS row and the slot is then overwritten with
+// -inf before the row is read into registers, so the row the loops see has e_x0 = 0: the running sums over the
+// other classes (R0 = sum_{j != x0} e_j^2, which must not be formed as a difference) need no per-class select, the
+// slot's generic terms are those of a class of zero probability (taken out again with the same expressions, bit for
+// bit), and the gradient loop leaves a zero in the slot, over which the token's own value for x0 is stored.
+// cs = grad_scale / npos, ces = ce_grad_scale / npos from the host.
+struct LvbGeneric { float qv, tj, d; };
+__device__ __forceinline__ LvbGeneric lvb_generic(float e2, float mo, float c3, float k1, float nc3) {
+  // s'_j = mo_j + c3 e_j^2;  qv = mo_j / s'_j;  tj = e_j^2 / s'_j (so that qv + c3 tj = 1);
+  // d_j = post_j / P_j - 1 = qv (rs - den) / den - c3 tj: both parts without cancellation
+  const float r = __builtin_amdgcn_rcpf(fmaf(e2, c3, mo));
+  LvbGeneric g;
+  g.qv = mo * r;
+  g.tj = e2 * r;
+  g.d = fmaf(g.qv, k1, g.tj * nc3);
+  return g;
+}
+
 template <int K, int LD, bool MSA, bool HYB>
-__global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* __restrict__ pred,
-                                                      const double* __restrict__ q, int tmax, int msa, float grad_scale,
-                                                      float ce_scale, double log_prior, double* __restrict__ part,
-                                                      double* __restrict__ per_seq, double* __restrict__ ce_seq,
-                                                      float* __restrict__ dpred) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_lvb_loss_tpl(ProtArgs a, const float* __restrict__ lvb32,
+                                                      const float* __restrict__ pred, const double* __restrict__ q,
+                                                      int tmax, int msa, float cs, float ces, double log_prior,
+                                                      double* __restrict__ part, double* __restrict__ per_seq,
+                                                      double* __restrict__ ce_seq, float* __restrict__ dpred) {
   using Img = RowImage<LD>;
   constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
+  constexpr int TR = MSA ? 9 : 5;                           // rows of the digest indexed by a token's classes
   extern __shared__ __align__(16) char lvb_rows[];          // [waves][64][STRIDE]
   __shared__ double red[HYB ? 16 : 8];
-  // per wave: a_diag, a_off (Q_t), mo, den diag / off (Qbar_t); MSA: rho diag / off, log rho diag / off
-  __shared__ float s_tab[8][MSA ? 9 : 5][32];
+  __shared__ float s_tab[8][TR][32];                        // a copy per wave: no workgroup barrier
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
@@ -424,33 +477,17 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
   float mo[K];
   float mdo = 0, sum_mo = 0;
   if (branch == 2) {
-    const int tm = min(t - 1, a.tb.T - 1), tq = min(t, a.tb.T - 1);
-    const double vd64 = lane < K ? dgd(a.tb.qbar_digest, tm, 0, K)[lane] : 0.0;
-    const double vo64 = lane < K ? dgd(a.tb.qbar_digest, tm, 1, K)[lane] : 0.0;
-    const float vd = (float)vd64, vo = (float)vo64;
-    if (lane < K) {
-      const double dd = dgd(a.tb.qbar_digest, tq, 0, K)[lane], dof = dgd(a.tb.qbar_digest, tq, 1, K)[lane];
-      s_tab[wave][0][lane] = (float)dgd(a.tb.qone_digest, tq, 0, K)[lane];
-      s_tab[wave][1][lane] = (float)dgd(a.tb.qone_digest, tq, 1, K)[lane];
-      s_tab[wave][2][lane] = vo;
-      s_tab[wave][3][lane] = (float)dd;
-      s_tab[wave][4][lane] = (float)dof;
-      if constexpr (MSA) {
-        // rho = Qbar_t[x0, x_t] / Qbar_{t-1}[x0, x_t] for x0 == x_t (diagonal) and x0 != x_t; a pair that
-        // Qbar_{t-1} gives no weight never occurs (x_t was drawn from it), its rho is left at zero
-        s_tab[wave][5][lane] = vd64 > 0.0 ? (float)(dd * rcp64(vd64)) : 0.0f;
-        s_tab[wave][6][lane] = vo64 > 0.0 ? (float)(dof * rcp64(vo64)) : 0.0f;
-        s_tab[wave][7][lane] = vd64 > 0.0 ? (float)(dgd(a.tb.qbar_digest, tq, 2, K)[lane] - dgd(a.tb.qbar_digest, tm, 2, K)[lane]) : 0.0f;
-        s_tab[wave][8][lane] = vo64 > 0.0 ? (float)(dgd(a.tb.qbar_digest, tq, 3, K)[lane] - dgd(a.tb.qbar_digest, tm, 3, K)[lane]) : 0.0f;
-      }
-    }
-    mdo = lane_broadcast(vd - vo, 0);
-    sum_mo = wave_sum(lane < K ? vo : 0.0f);
+    // (t is uniform over the workgroup: these are scalar loads)
+    const float* __restrict__ dg = lvb32 + (size_t)__builtin_amdgcn_readfirstlane(t) * (LVB_ROWS * 32);
+    if (lane < 32) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) mo[j] = lane_broadcast(vo, j);
+      for (int r = 0; r < TR; ++r) s_tab[wave][r][lane] = dg[r * 32 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) mo[j] = dg[2 * 32 + j];
+    mdo = dg[9 * 32];
+    sum_mo = dg[9 * 32 + 1];
   }
-  const float cs = grad_scale / (float)a.npos;
-  const float ces = HYB ? ce_scale / (float)a.npos : 0.0f;
   double acc = 0, acc_ce = 0;
   for (;; base += blockDim.x) {
     if (base >= p1) break;                                   // (uniform over the wave)
@@ -458,7 +495,8 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     x0 = clamp_index(x0, K);                                 // out-of-range tokens are clamped: nothing faults
     xt = clamp_index(xt, K);
     float e[LD];
-    float tok_loss = 0, tok_ce = 0, add0 = 0, addt = 0;
+    float tok_loss = 0, tok_ce = 0, set0 = 0, addt = 0;
+    bool set_x0 = false;                                     // (uniform) the x0 slot is stored, not added to
     auto from_q = [&]() {
       // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
       if (live && !q) acc = (double)NAN;                       // no probabilities given: NaN, nothing is read
@@ -474,85 +512,88 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     auto from_rows = [&]() {
       rows.deposit_flat(img, lane, ls);
       wave_lds_order();
-      Img::read_row(img, lane, e);
       const float z_x0 = *reinterpret_cast<const float*>(myrow + 4 * x0);
-      constexpr int KS = LD;                                 // classes of the softmax of this branch
       if (branch != 2) {
         // CrossEntropyLoss over all LD logits: the loss of an element at t == 1 (losses.py:54) and the driver's
         // second term (every element)
+        Img::read_row(img, lane, e);
         float m = e[0];
 #pragma unroll
-        for (int j = 1; j < KS; ++j) m = fmaxf(m, e[j]);
+        for (int j = 1; j < LD; ++j) m = fmaxf(m, e[j]);
         const float mneg = -m * LOG2E;
         float s = 0;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
+        for (int j = 0; j < LD; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
         tok_ce = fmaf(__builtin_amdgcn_logf(s), LN2, m - z_x0);
         tok_loss = branch == 0 ? tok_ce : 0.0f;                // (t == tmax: the element's term went to acc above)
         const float w = (branch == 0 ? cs : 0.0f) + ces;
         const float wi = w * __builtin_amdgcn_rcpf(s);
 #pragma unroll
-        for (int j = 0; j < KS; ++j) e[j] *= wi;
-        add0 = -w;
+        for (int j = 0; j < LD; ++j) e[j] *= wi;
+        set0 = -w;                                             // (added to the slot: set_x0 stays false)
       } else {
         const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
+        *reinterpret_cast<float*>(myrow + 4 * x0) = -INFINITY;  // after both reads (a wave's LDS operations are in order)
+        wave_lds_order();
+        Img::read_row(img, lane, e);
         float m = e[0];
 #pragma unroll
         for (int j = 1; j < K; ++j) m = fmaxf(m, e[j]);
+        m = fmaxf(m, z_x0);
         const float mneg = -m * LOG2E;
         float s = 0, R0 = 0;                                   // R0 = sum of e_j^2 over the classes other than x0
-        float e2[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
           e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg));
           s += e[j];
-          e2[j] = e[j] * e[j];
-          R0 += (j == x0) ? 0.0f : e2[j];
+          R0 = fmaf(e[j], e[j], R0);
         }
         const float e_x0 = __builtin_amdgcn_exp2f(fmaf(z_x0, LOG2E, mneg)), e_xt = __builtin_amdgcn_exp2f(fmaf(z_xt, LOG2E, mneg));
-        const float E2 = fmaf(e_x0, e_x0, R0);
+        s += e_x0;
+        const float ee_x0 = e_x0 * e_x0, ee_xt = e_xt * e_xt;
+        const float E2 = ee_x0 + R0;
         const float inv = __builtin_amdgcn_rcpf(s), inv2 = inv * inv;
         const float S2 = E2 * inv2;
-        const float c3 = mdo * __builtin_amdgcn_rcpf(E2);
+        const float c3 = mdo * __builtin_amdgcn_rcpf(E2), nc3 = -c3;
         const float a_d = s_tab[wave][0][xt], a_o = s_tab[wave][1][xt], da = a_d - a_o;
         const float mo_x0 = s_tab[wave][2][x0], mo_xt = s_tab[wave][2][xt];
         const bool same_b = x0 == xt;
         const float same = same_b ? 1.0f : 0.0f;
         const float den = same_b ? s_tab[wave][3][xt] : s_tab[wave][4][xt];
         const float iden = __builtin_amdgcn_rcpf(den);
-        const float w1 = c3 * R0, w2 = c3 * e_xt * e_xt;             // b_x0 - s'_x0 and s'_xt - mo_xt, both >= 0
-        const float sp_x0 = fmaf(e_x0 * e_x0, c3, mo_x0), sp_xt = mo_xt + w2;                     // s'_x0, s'_xt
+        const float w1 = c3 * R0, w2 = c3 * ee_xt;                    // b_x0 - s'_x0 and s'_xt - mo_xt, both >= 0
+        const float sp_x0 = fmaf(ee_x0, c3, mo_x0), sp_xt = mo_xt + w2;                           // s'_x0, s'_xt
         const float Sm = a_o * (sum_mo + mdo);
         const float rs = fmaf(da, sp_xt, Sm);                        // rsum' (sum_j s'_j = sum_mo + mdo)
         // Every ratio post_j / P_j = mo_j rs / (s'_j den) is taken as 1 + d_j with
-        //   d_j = (mo_j (rs - den) - (mdo / E2) e_j^2 den) / (s'_j den),
+        //   d_j = (mo_j (rs - den) - (mdo / E2) e_j^2 den) / (s'_j den) = qv_j (rs - den) / den - c3 tj_j,
         // rs - den = da w2 (x0 != x_t) or -da w1 (x0 == x_t) known without cancellation (den = Sm + da B_xt, the way
         // Qbar_t is built from Qbar_{t-1}): the first-order parts of the terms cancel in the sum over classes, so a
         // logarithm of the rounded ratio (6e-8 absolute) would leave an error of that size in a sum that can be
         // far smaller.
-        const float Dl = same_b ? -da * w1 : da * w2, cdn = -c3 * den;
+        const float Dl = same_b ? -da * w1 : da * w2, k1 = Dl * iden;
         float qv[K], G1 = 0, Hq = 0, Hp = 0;
         // (One logarithm for several classes of equal weight, as the image kernel takes it, does not carry over: a
         // product of the ratios kept as 1 + D loses the factor's relative accuracy wherever a ratio is far below
         // one (early timesteps), and kept as a plain product it is rounded against one (late timesteps).)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          const float sp = fmaf(e2[j], c3, mo[j]);
-          const float r = __builtin_amdgcn_rcpf(sp);
-          qv[j] = mo[j] * r;                                          // mo_j / s'_j
-          const float d = fmaf(e2[j], cdn, mo[j] * Dl) * (r * iden);
-          G1 = fmaf(mo[j], log2_1p(d), G1);
-          Hq = fmaf(mo[j], qv[j], Hq);
-          Hp = fmaf(e2[j], qv[j], Hp);
+          const LvbGeneric g = lvb_generic(e[j] * e[j], mo[j], c3, k1, nc3);
+          qv[j] = g.qv;
+          G1 = fmaf(mo[j], log2_1p(g.d), G1);
+          Hq = fmaf(mo[j], g.qv, Hq);
+          Hp = fmaf(mo[j], g.tj, Hp);                                 // sum_j e_j^2 qv_j
         }
         // special classes: x0 has B = mo + mdo, x_t has A = a_diag (both at once when x0 == x_t)
         const float r_x0 = __builtin_amdgcn_rcpf(sp_x0), r_xt = __builtin_amdgcn_rcpf(sp_xt);
         const float b_x0 = mo_x0 + mdo, a_x0 = fmaf(same, da, a_o);
-        // class x0 as a generic class (the same expression as in the loop, so that its term there is cancelled bit
-        // for bit), then with its own B = mo + mdo; class x_t with A = a_diag.  Their d without cancellation:
+        // the slot of x0 as the loop saw it (a generic class with e = 0: the same expressions, so that its terms
+        // cancel bit for bit), then the class with its own B = mo + mdo; class x_t with A = a_diag.  Their d
+        // without cancellation:
         //   x0 == x_t:  d0 = w1 Sm / (s'_x0 den)
         //   otherwise:  d0 = (w1 den + da w2 b_x0) / (s'_x0 den),   dt = -w2 Sm / (s'_xt den)
-        const float lg_x0 = log2_1p(fmaf(e_x0 * e_x0, cdn, mo_x0 * Dl) * (r_x0 * iden));
+        const LvbGeneric g0s = lvb_generic(0.0f, mo_x0, c3, k1, nc3);
+        const float lg_x0 = log2_1p(g0s.d);
         const float d0r = (same_b ? w1 * Sm : fmaf(w1, den, da * w2 * b_x0)) * r_x0 * iden;
         const float dtr = -w2 * Sm * r_xt * iden;
         const float lb_x0 = log2_1p(d0r);
@@ -567,24 +608,24 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
           rho = same_b ? s_tab[wave][5][xt] : s_tab[wave][6][xt];
           tok_loss = rho * ((same_b ? s_tab[wave][7][xt] : s_tab[wave][8][xt]) + tok_loss);
         }
-        // gradient
+        // gradient: gs_j = g0 - g1 qv_j for the generic slots (the slot of x0 among them, with e = 0), the exact
+        // values gx0 at x0 and gxt at x_t
         const float b_xt = fmaf(same, mdo, mo_xt);
         const float psum = iden * fmaf(a_o, sum_mo + mdo, da * b_xt);
         const float iS2 = __builtin_amdgcn_rcpf(S2), irs = __builtin_amdgcn_rcpf(rs);
         const float k = (MSA ? cs * rho : cs) * iS2;
         const float g0 = a_o * k * psum * irs, g1 = a_o * k * iden;
         const float gx0 = a_x0 * k * (psum * irs - b_x0 * iden * r_x0);          // exact gs at x0
-        const float d0 = gx0 - (g0 - g1 * mo_x0 * r_x0);
+        const float d0 = gx0 - (g0 - g1 * g0s.qv);                                // over the slot's generic value
         const float gxt = a_d * k * (psum * irs - mo_xt * iden * r_xt);          // exact gs at x_t (x_t != x0)
         const float dt = (1.0f - same) * (gxt - (g0 - g1 * mo_xt * r_xt));
-        const float pp_x0 = e_x0 * e_x0 * inv2, pp_xt = e_xt * e_xt * inv2;
+        const float pp_x0 = ee_x0 * inv2, pp_xt = ee_xt * inv2;
         const float W = fmaf(g0, sum_mo, fmaf(-g1, Hq, fmaf(d0, mo_x0, dt * mo_xt)));
-        const float Sg = fmaf(inv2, fmaf(g0, E2, -g1 * Hp), fmaf(pp_x0, d0, pp_xt * dt));    // sum_i p_i^2 gs_i
+        const float Sg = fmaf(inv2, fmaf(g0, R0, -g1 * Hp), fmaf(pp_x0, gx0, pp_xt * dt));   // sum_i p_i^2 gs_i
         const float dot = 2.0f * fmaf(W, S2, mdo * Sg);
         const float c4 = 2.0f * inv2 * fmaf(mdo, g0, W), c5 = 2.0f * inv2 * mdo * g1;
         float c6 = inv * dot;
-        add0 = 2.0f * pp_x0 * mdo * d0;
-        addt = 2.0f * pp_xt * mdo * dt;
+        float ce_x0 = 0.0f;
         if constexpr (HYB) {
           // softmax over all LD logits from the K exponentials at hand: softmax_j = e_j f / S_all
           float S_all = s, f = 1.0f, m_all = m;
@@ -602,15 +643,19 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
           tok_ce = fmaf(__builtin_amdgcn_logf(S_all), LN2, m_all - z_x0);
           const float wi = ces * __builtin_amdgcn_rcpf(S_all);
           c6 = fmaf(-wi, f, c6);
-          add0 -= ces;
+          ce_x0 = -ces;
 #pragma unroll
           for (int j = K; j < LD; ++j) e[j] *= wi;
         } else {
 #pragma unroll
           for (int j = K; j < LD; ++j) e[j] = 0.0f;
         }
+        // the token's own value for x0 (stored over the loop's zero) and the extra of x_t (added)
+        set0 = fmaf(2.0f * pp_x0, fmaf(mdo, gx0, W), fmaf(-c6, e_x0, ce_x0));
+        addt = 2.0f * pp_xt * mdo * dt;
+        set_x0 = true;
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] = fmaf(e2[j], fmaf(-c5, qv[j], c4), -c6 * e[j]);
+        for (int j = 0; j < K; ++j) e[j] *= fmaf(e[j], fmaf(-c5, qv[j], c4), -c6);
       }
       acc += live ? (double)tok_loss : 0.0;
       if constexpr (HYB) acc_ce += live ? (double)tok_ce : 0.0;
@@ -629,12 +674,17 @@ __global__ __launch_bounds__(512) void k_lvb_loss_tpl(ProtArgs a, const float* _
     }
     // gradient rows back through the image; the special classes are patched in the lane's own row
     Img::write_row(img, lane, e);
-    *reinterpret_cast<float*>(myrow + 4 * x0) += add0;
+    if (set_x0) *reinterpret_cast<float*>(myrow + 4 * x0) = set0;
+    else *reinterpret_cast<float*>(myrow + 4 * x0) += set0;
     *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
     wave_lds_order();
     Img::store_flat(img, drow + (size_t)base * Img::RB, min(64u, p1 - base), lane, ls);
     if (base + blockDim.x >= p1) break;
     wave_lds_order();
+    // (the next pass's rows are requested here, where the pass's registers are free: requested right after the
+    // deposit instead they travel while the pass computes, but hold 26 more registers through it -- 200 against
+    // 168, two waves per SIMD against three in the 256-thread launches: 39.5 against 41.3 us at B = 2048 and
+    // 6.86 against 6.60 us at B = 256; held to 168 registers that variant spills, 59 us)
     issue(base + blockDim.x);
   }
   acc = wave_sum(acc);
@@ -1127,6 +1177,17 @@ extern "C" int d3pm_corrupt(const d3pm_tables_f64* tb, const int64_t* x0, const 
   });
 }
 
+extern "C" size_t d3pm_lvb_digest_f32_size(int T) { return (size_t)(T > 0 ? T : 0) * LVB_ROWS * 32 * sizeof(float); }
+
+extern "C" int d3pm_lvb_digest_f32(const d3pm_tables_f64* tb, float* out, void* stream) {
+  D3PM_CHECK_ARG(tb && tb->qbar_digest && tb->qone_digest && out, "null pointer");
+  D3PM_CHECK_ARG(tb->K >= 2 && tb->K <= 32 && tb->T >= 1, "the float32 loss digest holds up to 32 classes (K=%d, T=%d)",
+                 tb->K, tb->T);
+  hipLaunchKernelGGL(k_lvb_digest32, dim3(tb->T), dim3(64), 0, (hipStream_t)stream, *tb, out);
+  D3PM_LAUNCH_CHECK("k_lvb_digest32");
+  return D3PM_OK;
+}
+
 extern "C" size_t d3pm_lvb_loss_workspace(int B, long npos, int K) {
   (void)K;
   long passes = npos > 0 ? npos : 1;
@@ -1150,7 +1211,7 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
   // training form (both D3PMLVBLoss and its MSA variant): one token per lane, float32 (K = 22 with rows of 22 or
   // 24 logits, the two alphabets of the reference's denoisers); every other shape, and forward-only evaluation,
   // on the float64 kernel
-  if (dpred && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
+  if (dpred && tb->lvb_digest && tb->K == 22 && (ld == 22 || ld == 24) && ((uintptr_t)pred & 15) == 0 &&
       ((uintptr_t)dpred & 15) == 0 && npos * ld < 0x1fffffffL) {
     ProtArgs a = make_prot(tb, x0, x_t, t, B, npos, 1);
     int block;
@@ -1186,8 +1247,9 @@ static int lvb_loss_impl(const d3pm_tables_f64* tb, const float* pred, long ld, 
         hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       }
-      hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, pred, q, tmax, msa, (float)grad_scale,
-                         (float)ce_grad_scale, log_prior, part, per_seq, ce_seq, dpred);
+      hipLaunchKernelGGL(kern, dim3(B * a.chunks), dim3(block), sh, s, a, tb->lvb_digest, pred, q, tmax, msa,
+                         (float)(grad_scale / (double)npos), (float)(ce_grad_scale / (double)npos), log_prior, part, per_seq,
+                         ce_seq, dpred);
       D3PM_LAUNCH_CHECK("k_lvb_loss_tpl");
       return D3PM_OK;
     };

@@ -108,12 +108,18 @@ d3pm_tables_f32 image_tables(at::TensorList tables, int64_t K, int64_t T, bool s
   tb.qbar = get(2, "qbar"); tb.qoneT = get(3, "qoneT"); tb.qbarT = get(4, "qbarT");
   return tb;
 }
-d3pm_tables_f64 protein_tables(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T) {
+d3pm_tables_f64 protein_tables(const Tensor& qbar_digest, const Tensor& qone_digest, const Tensor& lvb_digest, int64_t K,
+                               int64_t T) {
   need_protein_tables(qbar_digest, qone_digest, K, T);
   need_device(qbar_digest, "qbar_digest"); need_device(qone_digest, "qone_digest");
   TORCH_CHECK(qbar_digest.scalar_type() == at::kDouble && qone_digest.scalar_type() == at::kDouble,
               "d3pm_mi355x: protein digests are float64");
-  return d3pm_tables_f64{(int)K, (int)T, qbar_digest.data_ptr<double>(), qone_digest.data_ptr<double>()};
+  const float* lvb = nullptr;
+  if (lvb_digest.defined() && lvb_digest.numel() > 0) {        // empty: no float32 loss digest (K > 32)
+    need_numel(lvb_digest, (int64_t)(d3pm_lvb_digest_f32_size((int)T) / sizeof(float)), "lvb_digest");
+    lvb = f32(lvb_digest, "lvb_digest");
+  }
+  return d3pm_tables_f64{(int)K, (int)T, qbar_digest.data_ptr<double>(), qone_digest.data_ptr<double>(), lvb};
 }
 std::pair<int, long> dims(const Tensor& tokens) {
   const int B = tokens.dim() ? (int)tokens.size(0) : 1;
@@ -444,6 +450,16 @@ std::tuple<Tensor, Tensor> digest_f64(const Tensor& table, double rtol) {
                            dg.data_ptr<double>(), viol.data_ptr<int>(), stream()));
   return {dg, viol};
 }
+// per-timestep float32 constants of the training form of the LVB loss, from the two float64 digests
+Tensor lvb_digest(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T) {
+  D3PM_GUARD(qbar_digest);
+  auto tb = protein_tables(qbar_digest, qone_digest, Tensor(), K, T);
+  Tensor out = at::empty({T, (int64_t)(d3pm_lvb_digest_f32_size(1) / (32 * sizeof(float))), 32},
+                         qbar_digest.options().dtype(at::kFloat));
+  check_rc(d3pm_lvb_digest_f32(&tb, out.data_ptr<float>(), stream()));
+  return out;
+}
+
 // content fingerprints of several same-device float64 tables in one tensor (int64 [n]): the cache key of callers
 // that are handed fresh copies of their tables on every call (notebook cell-12)
 Tensor table_fingerprints(at::TensorList tables) {
@@ -480,11 +496,11 @@ ProtShape check_prot_args(const Tensor& pred, const Tensor* x0, const Tensor& x_
 }
 
 // D3PMLVBLoss.forward / D3PMLVBLossMSA.forward per batch element, protein_generation/losses.py:48-155
-std::tuple<Tensor, Tensor> lvb_loss(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T,
+std::tuple<Tensor, Tensor> lvb_loss(const Tensor& qbar_digest, const Tensor& qone_digest, const Tensor& lvb_digest, int64_t K, int64_t T,
                                     const Tensor& pred, const Tensor& x0, const Tensor& x_t, const Tensor& t,
                                     const OptTensor& q, int64_t tmax, int64_t msa, double grad_scale, bool want_grad) {
   D3PM_GUARD(pred);
-  auto tb = protein_tables(qbar_digest, qone_digest, K, T);
+  auto tb = protein_tables(qbar_digest, qone_digest, lvb_digest, K, T);
   auto [B, npos] = check_prot_args(pred, &x0, x_t, t, K);
   need_numel(q, (int64_t)B * npos * K, "q");
   TORCH_CHECK(tok_bytes(x0, "x0") == 8 && tok_bytes(x_t, "x_t") == 8 && tok_bytes(t, "t") == 8,
@@ -502,12 +518,12 @@ std::tuple<Tensor, Tensor> lvb_loss(const Tensor& qbar_digest, const Tensor& qon
 
 // the same with the driver's cross-entropy term (Protein Generation Notebook cell-12: (lvb + lambda ce) n_tokens):
 // returns (per_seq, ce_seq, dpred)
-std::tuple<Tensor, Tensor, Tensor> lvb_hybrid_loss(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T,
+std::tuple<Tensor, Tensor, Tensor> lvb_hybrid_loss(const Tensor& qbar_digest, const Tensor& qone_digest, const Tensor& lvb_digest, int64_t K, int64_t T,
                                                    const Tensor& pred, const Tensor& x0, const Tensor& x_t, const Tensor& t,
                                                    const OptTensor& q, int64_t tmax, int64_t msa, double grad_scale,
                                                    double ce_grad_scale, bool want_grad) {
   D3PM_GUARD(pred);
-  auto tb = protein_tables(qbar_digest, qone_digest, K, T);
+  auto tb = protein_tables(qbar_digest, qone_digest, lvb_digest, K, T);
   auto [B, npos] = check_prot_args(pred, &x0, x_t, t, K);
   need_numel(q, (int64_t)B * npos * K, "q");
   TORCH_CHECK(tok_bytes(x0, "x0") == 8 && tok_bytes(x_t, "x_t") == 8 && tok_bytes(t, "t") == 8,
@@ -525,11 +541,11 @@ std::tuple<Tensor, Tensor, Tensor> lvb_hybrid_loss(const Tensor& qbar_digest, co
 }
 
 // reverse step of generate_d3pm / generate_msa_d3pm, protein_generation/generate.py:28-40, :70-93
-Tensor lvb_reverse_step(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T, const Tensor& pred,
+Tensor lvb_reverse_step(const Tensor& qbar_digest, const Tensor& qone_digest, const Tensor& lvb_digest, int64_t K, int64_t T, const Tensor& pred,
                         const Tensor& x_t, const Tensor& t, const OptTensor& expo, int64_t seed, int64_t offset,
                         const OptTensor& offset_dev, double last_class_div, int64_t exclude_last_prefix) {
   D3PM_GUARD(pred);
-  auto tb = protein_tables(qbar_digest, qone_digest, K, T);
+  auto tb = protein_tables(qbar_digest, qone_digest, lvb_digest, K, T);
   auto [B, npos] = check_prot_args(pred, nullptr, x_t, t, K);
   need_numel(expo, (int64_t)B * npos * K, "expo");
   need_counter(offset_dev, "offset_dev");
@@ -543,11 +559,11 @@ Tensor lvb_reverse_step(const Tensor& qbar_digest, const Tensor& qone_digest, in
 }
 
 // batched sample_transition_matrix as the collaters use it, protein_generation/utils.py:44-52, dataset.py:234-242
-std::tuple<Tensor, Tensor> corrupt(const Tensor& qbar_digest, const Tensor& qone_digest, int64_t K, int64_t T,
+std::tuple<Tensor, Tensor> corrupt(const Tensor& qbar_digest, const Tensor& qone_digest, const Tensor& lvb_digest, int64_t K, int64_t T,
                                    const Tensor& x0, const Tensor& t, const OptTensor& expo, int64_t seed, int64_t offset,
                                    bool want_probs) {
   D3PM_GUARD(x0);
-  auto tb = protein_tables(qbar_digest, qone_digest, K, T);
+  auto tb = protein_tables(qbar_digest, qone_digest, lvb_digest, K, T);
   auto [B, npos] = dims(x0);
   need_numel(t, B, "t");
   need_numel(expo, (int64_t)B * npos * K, "expo");
@@ -564,7 +580,7 @@ std::tuple<Tensor, Tensor> corrupt(const Tensor& qbar_digest, const Tensor& qone
 }  // namespace
 
 #define D3PM_TB "Tensor[] tables, int K, int T, bool structured, float eps, "
-#define D3PM_PT "Tensor qbar_digest, Tensor qone_digest, int K, int T, "
+#define D3PM_PT "Tensor qbar_digest, Tensor qone_digest, Tensor lvb_digest, int K, int T, "
 #define D3PM_LOSS_ARGS "Tensor logits, Tensor x0, Tensor x_t, Tensor t, int loss_type, float hybrid_coeff, float grad_scale, "
 
 TORCH_LIBRARY(d3pm_mi355x, m) {
@@ -593,6 +609,7 @@ TORCH_LIBRARY(d3pm_mi355x, m) {
   m.def("digest_f64(Tensor table, float rtol) -> (Tensor, Tensor)");
   m.def("table_to_f32(Tensor table) -> Tensor");
   m.def("table_fingerprints(Tensor[] tables) -> Tensor");
+  m.def("lvb_digest(Tensor qbar_digest, Tensor qone_digest, int K, int T) -> Tensor");
   m.def("lvb_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
         "float grad_scale, bool want_grad) -> (Tensor, Tensor)");
   m.def("lvb_hybrid_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
@@ -624,6 +641,7 @@ TORCH_LIBRARY_IMPL(d3pm_mi355x, CUDA, m) {
   m.impl("digest_f64", digest_f64);
   m.impl("table_to_f32", table_to_f32);
   m.impl("table_fingerprints", table_fingerprints);
+  m.impl("lvb_digest", lvb_digest);
   m.impl("lvb_loss", lvb_loss);
   m.impl("lvb_hybrid_loss", lvb_hybrid_loss);
   m.impl("lvb_reverse_step", lvb_reverse_step);

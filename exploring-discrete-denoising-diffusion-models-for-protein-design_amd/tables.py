@@ -93,14 +93,18 @@ class ProteinTables:
             raise NotImplementedError(
                 "protein-style kernels need column-structured transition tables (uniform schedule); "
                 f"{self.violations} entries break the structure")
-        self._desc = _lib.TablesF64(K, T, ptr(self.qbar_digest), ptr(self.qone_digest))
+        # float32 constants of the training form of the LVB loss (alphabets of up to 32 classes)
+        self.lvb_digest = ops.lvb_digest(self.qbar_digest, self.qone_digest, K, T) if K <= 32 else \
+            torch.empty(0, dtype=torch.float32, device=self.device)
+        self._desc = _lib.TablesF64(K, T, ptr(self.qbar_digest), ptr(self.qone_digest),
+                                    ptr(self.lvb_digest) if self.lvb_digest.numel() else None)
 
     def desc(self):
         return C.byref(self._desc)
 
     def op_args(self):
         """Leading arguments of the torch.ops.d3pm_mi355x protein-style operators."""
-        return (self.qbar_digest, self.qone_digest, self.K, self.T)
+        return (self.qbar_digest, self.qone_digest, self.lvb_digest, self.K, self.T)
 
 
 # Two keys lead to a ProteinTables: the identity of the caller's tensors (storage pointer + version: no device work

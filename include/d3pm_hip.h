@@ -141,7 +141,19 @@ typedef struct d3pm_tables_f64 {
   int K, T;
   const double* qbar_digest; /* [T][4][K] of Q_bar: diag, off, log(diag), log(off) */
   const double* qone_digest; /* [T][4][K] of Q_t   */
+  const float* lvb_digest;   /* d3pm_lvb_digest_f32 of the two, or NULL (K > 32, or a
+                                caller that does not train): the float32 training form
+                                of d3pm_lvb_loss then falls back to the float64 kernel */
 } d3pm_tables_f64;
+
+/* Per-timestep constants of the float32 training form of d3pm_lvb_loss, from
+ * the two float64 digests of `tb` (its lvb_digest member is not read): for the
+ * loss at timestep t the column of Q_t, the off-diagonal of Qbar_{t-1}, the
+ * entries Qbar_t[x0, x_t] that losses.py:79 divides by (and their ratio to
+ * those of Qbar_{t-1}, losses.py:148), formed in float64 and rounded once.
+ * out: d3pm_lvb_digest_f32_size(T) bytes on the device.  K <= 32. */
+size_t d3pm_lvb_digest_f32_size(int T);
+int d3pm_lvb_digest_f32(const d3pm_tables_f64* tb, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Image-style process (d3pm/diffusion_discrete.py)

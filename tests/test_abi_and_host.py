@@ -51,9 +51,9 @@ def test_torch_ops_registered(pkg):
 
 
 def test_struct_layout_matches_header(pkg):
-    # d3pm_tables_f32: 3 ints + float + 5 pointers; d3pm_tables_f64: 2 ints + 2 pointers
+    # d3pm_tables_f32: 3 ints + float + 5 pointers; d3pm_tables_f64: 2 ints + 3 pointers
     assert ctypes.sizeof(pkg._lib.TablesF32) == 16 + 5 * 8
-    assert ctypes.sizeof(pkg._lib.TablesF64) == 8 + 2 * 8
+    assert ctypes.sizeof(pkg._lib.TablesF64) == 8 + 3 * 8
 
 
 def test_generate_betas_matches_golden(pkg):

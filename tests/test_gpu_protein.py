@@ -509,16 +509,17 @@ def test_reverse_step_device_noise_distribution(pkg, tables500, n_tok):
             assert (np.abs(freq - Pm) < 5 * np.sqrt(Pm * (1 - Pm) / n) + 1e-5).all(), (w_last, freq, Pm)
 
 
-@pytest.mark.parametrize("n_tok", [22, 24])
-def test_reverse_step_device_noise_at_sampler_shape(pkg, tables500, n_tok):
-    """The reverse step at the shape the sampling benchmark runs (1024 sequences x 263 positions, rows of 22 or 24
-    logits; 263 = 4 x 64 + 7 leaves a ragged last wave): every position has its own logits row and x_t, the
-    1024 sequences are its sample; per-position class frequencies against the oracle's marginal."""
+@pytest.mark.parametrize("n_tok,Bn", [(22, 1024), (24, 1024), (22, 1250), (24, 1250)])
+def test_reverse_step_device_noise_at_sampler_shape(pkg, tables500, n_tok, Bn):
+    """The reverse step at the shapes the sampling drivers run (1024 sequences x 263 positions = 4208 full waves of
+    the flat layout, and the benchmark's own sub-batch of 1250 sequences = 5136 waves + a tail of 46 tokens; rows of
+    22 or 24 logits): every position has its own logits row and x_t, the sequences are its sample; per-position
+    class frequencies against the oracle's marginal."""
     from d3pm_amd.protein_generation.generate import reverse_step
     from d3pm_amd.tables import protein_tables
     tok, Qb, Qt = tables500
     tb = protein_tables(Qt, Qb)
-    Bn, Ln = 1024, 263
+    Ln = 263
     gen = torch.Generator().manual_seed(17 + n_tok)
     for t in (499, 250, 2):
         rows = torch.randn(Ln, n_tok, generator=gen) * 2.0

@@ -122,6 +122,14 @@ def main():
     timed("corrupt", corrupt, 16 * BP * LP, "d3pm_corrupt (device noise), 16 B/token")
     timed("lvb", lvb, (8 * LDP + 16) * BP * LP, "d3pm_lvb_loss fwd+bwd, n_tokens=24, 8 ld+16 B/token")
 
+    cep = torch.empty(BP, dtype=torch.float64, device=dev)
+
+    def lvb_ce():           # the training loop's loss: (lvb + 0.001 ce) * n_tokens, one launch
+        check(lib.d3pm_lvb_hybrid_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 0,
+                                       float(LP), 0.001 * LP, ptr(perp), ptr(cep), ptr(dpp), ptr(wsp), wsbp, sp))
+    timed("lvb_ce", lvb_ce, (8 * LDP + 16) * BP * LP,
+          "d3pm_lvb_hybrid_loss fwd+bwd (LVB + cross-entropy of every token), n_tokens=24, 8 ld+16 B/token")
+
     def lvb_msa():          # the same tokens taken as MSAs of depth 8 (D3PMLVBLossMSA: msa = depth)
         check(lib.d3pm_lvb_loss(ptab.desc(), ptr(predp), LDP, ptr(x0p), ptr(xtp), ptr(tp), None, BP, LP, 500, 8,
                                 1.0 / BP, ptr(perp), ptr(dpp), ptr(wsp), wsbp, sp))
@@ -140,7 +148,7 @@ def main():
     # ---- the same two losses at eight times the batch (the global batch of 2048 on one GPU: 1 M tokens, 285 / 218 MB
     # per launch, more than the 256 MiB Infinity Cache holds): what the kernels reach once the launch overhead and
     # the arrival of the first rows are a small part of the launch
-    if args.big or only & {"hybrid_b2048", "lvb_b2048"}:
+    if args.big or only & {"hybrid_b2048", "lvb_b2048", "lvb_ce_b2048"}:
         BB = 2048
         x0b = torch.randint(0, K, (BB, L, 1, 1), device=dev)
         lgb = torch.randn(BB, L, 1, 1, K, device=dev)
@@ -172,6 +180,11 @@ def main():
             ptab.desc(), ptr(predq), LDP, ptr(x0q), ptr(xtq), ptr(tq), None, BB, LP, 500, 0, 1.0 / BB, ptr(perq),
             ptr(dpq), ptr(wsq), wsbq, sp)),
             (8 * LDP + 16) * BB * LP, "d3pm_lvb_loss fwd+bwd, n_tokens=24, B=2048 L=512")
+        ceq = torch.empty(BB, dtype=torch.float64, device=dev)
+        timed("lvb_ce_b2048", lambda: check(lib.d3pm_lvb_hybrid_loss(
+            ptab.desc(), ptr(predq), LDP, ptr(x0q), ptr(xtq), ptr(tq), None, BB, LP, 500, 0, float(LP), 0.001 * LP,
+            ptr(perq), ptr(ceq), ptr(dpq), ptr(wsq), wsbq, sp)),
+            (8 * LDP + 16) * BB * LP, "d3pm_lvb_hybrid_loss fwd+bwd, n_tokens=24, B=2048 L=512")
     print(json.dumps(rows))
 
 
