@@ -43,7 +43,10 @@ SUB_BATCH = 1250               # reverse sampling: sequences per graph replay (1
 # HBM bytes per launch of a kernel from the PMC passes kept under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, gfx950
 # correction); the newest committed profile that names the kernel wins.  Not measured by this run: counters need a
 # rocprofv3 pass of their own.
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_kernels_pmc_hbm.json", "r01_bench_pmc_hbm.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_kernels_pmc_hbm.json", "r02_kernels_pmc_hbm.json",
+                                                             "r01_bench_pmc_hbm.json")]
+# `rocprofv3 --kernel-trace --stats` of `bench.py --roofline-only` (the rotating-buffer launch sequence alone)
+TRACE_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_roofline_kernel_stats.csv",)]
 
 
 def measured_traffic(kernel: str, must_contain: str = ""):
@@ -57,6 +60,20 @@ def measured_traffic(kernel: str, must_contain: str = ""):
                     and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
                 return {"bytes": (2 * ctr["FETCH_SIZE"]["mean_per_launch"] + ctr["WRITE_SIZE"]["mean_per_launch"]) * 1024,
                         "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+def traced_duration_ms(kernel: str):
+    """Average duration of `kernel` in the newest committed rocprofv3 kernel trace of `bench.py --roofline-only`."""
+    import csv
+    for path in TRACE_FILES:
+        try:
+            rows = list(csv.DictReader(open(path)))
+        except OSError:
+            continue
+        for r in rows:
+            if kernel in r.get("Name", ""):
+                return {"ms": float(r["AverageNs"]) * 1e-6, "calls": int(r["Calls"]), "source": os.path.relpath(path, ROOT)}
     return None
 
 
@@ -385,6 +402,8 @@ def worker(args):
     # per example and d mean / d logits (one launch), gradient handed to autograd -- replayed as a HIP graph.
     # --compat: the reference-shaped calls, training_losses(...).mean().backward(), which add the caller's
     # reduction and its backward (four more short launches on [B] tensors).
+    compat_steps = 1                       # steps per graph of the reference-shaped call sequence
+
     def make_step(dd, compat, graph):
         if compat and not graph:
             def step():
@@ -395,7 +414,8 @@ def worker(args):
                 losses.mean().backward()                              # hands dlogits to autograd (early-exit rescale)
             return step
         if compat:
-            return d3pm_amd.graphs.GraphedTrainingLosses(dd, model_fn, x0, seed=1234 + rank, params=[logits]).replay
+            return d3pm_amd.graphs.GraphedTrainingLosses(dd, model_fn, x0, seed=1234 + rank, params=[logits],
+                                                         steps=compat_steps).replay
         if not graph:
             def step():
                 logits.grad = None
@@ -437,7 +457,11 @@ def worker(args):
     # for the record: the same n-step graph with two launches per step (captured here: before the process group)
     plain_multi = (d3pm_amd.graphs.GraphedTrainingStep(d, model_fn, x0, seed=99 + rank, params=[logits], steps=spg).replay
                    if pipelined and not args.no_secondary else None)
+    # the call shape that is not timed, for the record, at the same number of steps per graph as the timed one
+    compat_steps = spg if (not args.compat and not args.no_graph) else 1
     other = make_step(d, not args.compat, not args.no_graph) if not args.no_secondary else None
+    other_steps = compat_steps if not args.compat else 1
+    compat_steps = 1
     d_abs = run_abs = None
     if not args.no_secondary and rank == 0:
         d_abs = process("absorbing" if args.kind == "uniform" else "uniform")
@@ -551,7 +575,7 @@ def worker(args):
         for _ in range(100):
             other()
         torch.cuda.synchronize()
-        other_ms = (time.perf_counter() - o0) * 10.0
+        other_ms = (time.perf_counter() - o0) * 10.0 / other_steps
 
     progress("fused kernel back to back")
     kern_ms = fused_kernel_ms(d)
@@ -819,6 +843,16 @@ def worker(args):
                         "*_cache_resident: one 35.7 MB working set relaunched back to back, which stays in the "
                         "256 MiB Infinity Cache; `bench.py --roofline-only` launches exactly the rotating sequence "
                         "(the program of the committed rocprofv3 kernel trace)"}
+        traced = traced_duration_ms("k_hybrid_loss_pair32<true, false>")
+        if traced:
+            # the tracer serialises the dispatches and brackets each with its own packets: a kernel of this size
+            # reads 0.4-0.5 us longer under it than its back-to-back rate, which is what the events (and the wall
+            # clock of the replayed graph) see; both are given so that either division can be checked
+            roof["kernel_ms_rocprof_trace"] = traced["ms"]
+            roof["frac_rocprof_trace"] = BYTES_PER_TOKEN * B * L / (traced["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["rocprof_trace_source"] = (f"{traced['source']}: {traced['calls']} launches of `bench.py "
+                                            "--roofline-only` under rocprofv3 --kernel-trace (a committed trace, not "
+                                            "measured by this run)")
         if kern_replayed_ms:
             roof["kernel_ms_graph_replayed"] = kern_replayed_ms
             roof["frac_graph_replayed"] = BYTES_PER_TOKEN * B * L / (kern_replayed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -844,7 +878,9 @@ def worker(args):
                        "timed_steps": n_timed, "timed_repeats_of_steps": reps, "timed_seconds": elapsed,
                        "one_step_per_graph_ms_per_step": single_ms,
                        "calls": "training_losses(...).mean().backward()" if args.compat else "training_step(...)",
-                       "other_call_shape_ms_per_step": other_ms},
+                       "other_call_shape_ms_per_step": other_ms,
+                       "other_call_shape": ("training_step(...)" if args.compat else
+                                            f"training_losses(...).mean().backward(), {other_steps} step(s) per graph")},
             "roofline": roof,
             "absorbing": absorbing,
             "reverse_sample": reverse,

@@ -100,6 +100,15 @@ class _LogisticLogits(torch.autograd.Function):
         return dloc, dls, None, None
 
 
+def _upstream(g: torch.Tensor) -> torch.Tensor:
+    """The upstream gradient of a per-example loss as the rescale kernel takes it: float32, dense -- or ONE element
+    when every batch element got the same value (``.mean()`` / ``.sum()`` hand down an expanded scalar: stride 0),
+    which rescales the whole gradient by that value and needs no copy of the expanded tensor."""
+    if g.dim() == 1 and g.numel() > 1 and g.stride(0) == 0:
+        g = g[:1]
+    return g.contiguous().float()
+
+
 class _FusedLoss(torch.autograd.Function):
     """loss[B] = (vb | ce | vb + lambda*ce) of one batch; d loss / d logits is
     produced by the same kernel with `baked` as upstream gradient and rescaled
@@ -126,12 +135,13 @@ class _FusedLoss(torch.autograd.Function):
         dl = ctx.dl
         if dl is None:
             return (None,) * 10
-        g = g.contiguous().float()
+        g = _upstream(g)
         if getattr(ctx, "spent", False):
             # the first backward gave its buffer away (rescaled in place): recompute the gradient with this
             # upstream gradient passed to the kernel
             lg, x0, x_t, t, tables, loss_type, lam = ctx.again
-            dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, lam, 1.0, g, True)[3]
+            gb = g if g.numel() == x0.shape[0] else g.expand(x0.shape[0]).contiguous()
+            dl = ops.hybrid_loss(*tables.op_args(), lg, x0, x_t, t, loss_type, lam, 1.0, gb, True)[3]
         else:
             ctx.spent = True
             ops.scale_rows_(dl, g, ctx.baked)

@@ -23,12 +23,17 @@ class GraphedTrainingLosses:
     ``params`` lists those leaf tensors: their ``.grad`` is cleared before the
     capture so that the captured backward writes gradients instead of
     accumulating into the warm-up's (one elementwise pass less per step); read
-    ``p.grad`` after ``replay()``.
+    ``p.grad`` after ``replay()``.  ``steps`` > 1 captures that many consecutive
+    steps in one graph (one host-side graph launch for all of them; ``params``'
+    gradients are cleared before each captured step, so after a replay they hold
+    the last step's gradient).
     """
 
-    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0, warmup: int = 3, params=()):
+    def __init__(self, diffusion, model_fn, x_start: torch.Tensor, seed: int = 0, warmup: int = 3, params=(),
+                 steps: int = 1):
         self.diffusion, self.model_fn, self.x_start = diffusion, model_fn, x_start
         self.seed = int(seed)
+        self.steps = int(steps)
         dev = x_start.device
         # parameters usually predate the capture stream; the mismatch torch warns about is intended here
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -46,8 +51,12 @@ class GraphedTrainingLosses:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._body()
-            self.loss.backward()
+            for i in range(self.steps):
+                if i:
+                    for p in params:
+                        p.grad = None
+                self.loss = self._body()
+                self.loss.backward()
 
     def _body(self):
         # (the loss launch advances the Philox counter: no bookkeeping launch in the graph)

@@ -18,6 +18,7 @@ from .._ops import ops
 from ..tables import protein_tables
 from .constants import MSA_AAS
 from .utils import Tokenizer
+from ..d3pm.diffusion_discrete import _upstream
 
 
 def sample_prior(a, b, len=len(MSA_AAS)):
@@ -70,7 +71,7 @@ class _LVB(torch.autograd.Function):
         dp = ctx.dp
         if dp is None:
             return (None,) * 10
-        g = g.contiguous().float()
+        g = _upstream(g)
         baked = ctx.baked
         if getattr(ctx, "spent", False):
             # the first backward gave its buffer away (rescaled in place): recompute with unit scale

@@ -4,6 +4,8 @@
 #                                       (every hot kernel at the bench's shapes, eager launches)
 #   tools/collect_profiles.sh bench     kernel trace of bench.py --no-graph --no-secondary (the headline step)
 #   tools/collect_profiles.sh dense     kernel trace + matrix-core counters of the K=256 image configuration
+#   tools/collect_profiles.sh roofline  kernel trace of bench.py --roofline-only: the dominant kernel over ten rotating
+#                                       buffer sets and nothing else of it (the launch sequence roofline.frac is quoted on)
 # One counter group per run, each run a process of its own with its own time limit; the first failing step ends
 # the script.  Every profiled program launches eagerly: the kernels and their durations are those of the HIP-graph
 # replays, and the tracer sees plain single launches.  Results land in gpurun_out/prof_<what> (copy what is to be
@@ -37,6 +39,11 @@ kernels)
 bench)
   echo "== kernel trace of the bench step (eager)"
   timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench -- python3 -u $R/bench.py --no-graph --no-secondary --no-cpu-baseline --steps 100 --warmup 20 > $O/bench.json
+  ;;
+roofline)
+  echo "== kernel trace of the rotating-buffer launch sequence"
+  timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o roofline -- python3 -u $R/bench.py --roofline-only > $O/roofline.json
+  cat $O/roofline.json
   ;;
 dense)
   K="$R/tools/kbench.py --kind gaussian --bits 8 --B 128 --L 1024"
