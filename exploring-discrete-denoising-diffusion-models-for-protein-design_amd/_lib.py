@@ -74,6 +74,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 9        # d3pm_abi_version() of the library these signatures describe
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -84,6 +87,10 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    have = lib.d3pm_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {have}, this binding was written for {ABI_VERSION}: rebuild it "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
     return lib
 
 
