@@ -1001,18 +1001,25 @@ struct NextQ {
   int32_t* t_out; int64_t* x_t;                // [B] and [B, npos]
 };
 
-template <bool GRAD, bool NEXT = false>
+// ONE: the workgroup's threads cover the whole batch element (npos <= blockDim.x / 2, every wave has tokens): the
+// pass loop is gone at compile time, and with it the loop-carried copies of the row registers and the zeroed rows
+// of the wave-without-work path (48 of 435 vector instructions per wave at npos = 512).
+template <bool GRAD, bool NEXT = false, bool ONE = false>
 __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
-    ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float grad_scale,
-    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float per_pos_bits, NextQ nx) {
-  // per_pos_bits = 1 / (npos ln 2), formed on the host: the kernel runs its set-up once per wave of 32 tokens
+    ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float w_vb0,
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float w_ce0, NextQ nx) {
+  // w_vb0 / w_ce0: the weights of the two loss terms in the gradient, grad_scale / (npos ln 2) times 1, 0 or the
+  // hybrid coefficient as the loss type says, formed on the host: the kernel runs its set-up once per wave of 32 tokens
   constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
   extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
-  __shared__ float red[2 * PW];
+  __shared__ __align__(8) float red[PW * 4 * 2];            // (vb, ce) of each 16-lane row of each wave
   __shared__ __align__(16) float s_tab[PW][3][KC];          // as in k_hybrid_loss_tpl: a copy per wave
+  __shared__ __align__(16) float s_w4[PW][KC / 4];          // (off + eps)^4 of the first class of every group of four
   const float eps = a.tb.eps;
   const int b = blockIdx.x;                                 // one workgroup per batch element
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index through the scalar unit: everything derived from it -- the wave's LDS image, its block of rows,
+  // the full-wave tests -- is then scalar arithmetic and scalar branches)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane & 1, ptok = lane >> 1;
   const unsigned p1 = (unsigned)a.npos;
   const unsigned step = blockDim.x >> 1;                    // tokens per pass of the workgroup
@@ -1023,6 +1030,9 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
   char* const img = pair_rows + (size_t)wave * 64 * HS;
   char* const myhalf = img + lane * HS;                     // half-row index = lane
+  // piece h of this lane in the wave's block of rows (16 bytes at byte 1024 h + 16 lane of it) belongs to half-row
+  // 16 h + lane / 4, 16-byte piece lane % 4 of it
+  char* const piece0 = img + (lane >> 2) * HS + (lane & 3) * 16;
   char* const tokrow = img + (lane & ~1) * HS;              // class c of this token: tokrow + (c >> 4) * HS + 4 * (c & 15)
   auto cls_off = [](int c) { return (c >> 4) * HS + 4 * (c & 15); };
 
@@ -1099,7 +1109,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       __builtin_amdgcn_s_setprio(0);
     }
   }
-  if (base < p1) issue(base);
+  if (ONE || base < p1) issue(base);
   D3PM_TL_AFTER(1, t);
   const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
   unsigned same_w = 0;          // bit q: classes 4q .. 4q+3 of both halves have one off-diagonal weight each
@@ -1114,45 +1124,55 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   // this lane's per-class weights off_j + eps stay in the wave's LDS table and are read four at a time (a broadcast
   // read per group): sixteen registers less than keeping them, which is what this kernel is short of
   const v4f_nt* const my_boe = reinterpret_cast<const v4f_nt*>(&s_tab[wave][2][HC * half]);
-  const float gb = grad_scale * ((GRAD && grad_out) ? grad_out[b] : 1.0f);
-  const float cnorm = gb * per_pos_bits;
-  const float w_vb = (loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
-  const float w_ce = (loss_type == D3PM_LOSS_KL) ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
+  float w_vb = w_vb0, w_ce = w_ce0;
+  if (GRAD && grad_out) {                     // (uniform) an upstream gradient per batch element
+    const float go = grad_out[b];
+    w_vb *= go;
+    w_ce *= go;
+  }
   float acc_vb = 0, acc_ce = 0;
   bool first = true;
   for (;; base += step) {
-    const bool work = base < p1;              // uniform over the wave
-    float e[HC];
+    const bool work = ONE || base < p1;       // uniform over the wave
+    // the lane's 16 classes as eight pairs: the per-class arithmetic below is written on pairs so that it maps onto
+    // the packed float32 instructions (one issue slot for two classes)
+    f2v e[HC / 2];
     float m = 0, inv = 0, l2s = 0, mneg = 0;
     if (work) {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const unsigned q = h * 64 + lane;
-        *reinterpret_cast<v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16) = stage[h];
-      }
+      for (int h = 0; h < 4; ++h) *reinterpret_cast<v4f_nt*>(piece0 + h * 16 * HS) = stage[h];
       if (first && need_post && lane < KC) {
         // this wave's table copy goes to LDS together with the rows (the digest values were requested right behind
         // the rows and arrive with them): the fence below covers both, and nothing waits on LDS after phase A
+        const float bo = vo + eps, bo2 = bo * bo;
         s_tab[wave][0][lane] = v_ad + eps;
         s_tab[wave][1][lane] = v_ao + eps;
-        s_tab[wave][2][lane] = vo + eps;
+        s_tab[wave][2][lane] = bo;
+        s_w4[wave][lane >> 2] = bo2 * bo2;      // (four lanes, one slot: equal values wherever the slot is used)
       }
       if (first) D3PM_TL(2);
       wave_lds_fence();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const v4f_nt q = *reinterpret_cast<const v4f_nt*>(myhalf + 16 * j);
-        e[4 * j] = q.x; e[4 * j + 1] = q.y; e[4 * j + 2] = q.z; e[4 * j + 3] = q.w;
+        e[2 * j] = f2v{q.x, q.y};
+        e[2 * j + 1] = f2v{q.z, q.w};
       }
       // ---- phase A: softmax statistics (no timestep needed)
-      m = e[0];
+      m = fmaxf(e[0].x, e[0].y);
 #pragma unroll
-      for (int j = 1; j < HC; ++j) m = fmaxf(m, e[j]);
+      for (int j = 1; j < HC / 2; ++j) m = fmaxf(fmaxf(m, e[j].x), e[j].y);
       m = fmaxf(m, partner<1>(m));
       mneg = -m * LOG2E;
-      float s_ = 0;
+      const f2v mneg2 = {mneg, mneg}, l2e2 = {LOG2E, LOG2E};
+      f2v s2 = {0.0f, 0.0f};
 #pragma unroll
-      for (int j = 0; j < HC; ++j) { e[j] = fast_exp2(fmaf(e[j], LOG2E, mneg)); s_ += e[j]; }
+      for (int j = 0; j < HC / 2; ++j) {
+        const f2v a2 = e[j] * l2e2 + mneg2;
+        e[j] = f2v{fast_exp2(a2.x), fast_exp2(a2.y)};
+        s2 += e[j];
+      }
+      float s_ = s2.x + s2.y;
       s_ += partner<1>(s_);
       inv = fast_rcp(s_);
       l2s = fast_log2(s_);
@@ -1192,8 +1212,9 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       acc_vb += live ? ce_bits : 0.0f;
       if constexpr (GRAD) {
         const float w = (t == 0 ? w_vb : 0.0f) + w_ce, wi = w * inv;
+        const f2v wi2 = {wi, wi};
 #pragma unroll
-        for (int j = 0; j < HC; ++j) e[j] *= wi;
+        for (int j = 0; j < HC / 2; ++j) e[j] *= wi2;
         g_x0 = fmaf(e_x0, wi, -w);
         g_xt = (x0 == xt) ? g_x0 : e_xt * wi;
       }
@@ -1211,32 +1232,38 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
       const float Zm = fmaf(a_o, sum_boe + bdo, da * f2_xt);
       const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
       const float zr = Zm * izt;
-      float pr[HC], E = 0, S1 = 0;
+      f2v pr[HC / 2], E2 = {0.0f, 0.0f};
+      float S1 = 0;
+      const f2v bdoi2 = {bdoi, bdoi};
+      const v4f_nt w4 = *reinterpret_cast<const v4f_nt*>(&s_w4[wave][(HC / 4) * half]);
 #pragma unroll
       for (int q = 0; q < HC / 4; ++q) {
-        // the four reciprocals 1 / f2_j from one: r = 1 / (f0 f1 f2 f3), 1 / f0 = r (f2 f3) f1, ...  A transcendental
-        // costs four ordinary operations on this part; every f2_j lies in [eps, 2], so the product stays in range.
+        // the four reciprocals 1 / f_j from one: with p = (f0 f2, f1 f3) and r = 1 / (p.x p.y), (1/f0, 1/f1) =
+        // r (p.y, p.x) (f2, f3) and (1/f2, 1/f3) = r (p.y, p.x) (f0, f1): every step is one packed operation on the
+        // pairs as they lie in registers.  A transcendental costs three to four ordinary operations on this part;
+        // every f_j lies in [eps, 2], so the product stays in range.
         const v4f_nt w = my_boe[q];
-        const float f0 = fmaf(e[4 * q], bdoi, w.x), f1 = fmaf(e[4 * q + 1], bdoi, w.y);
-        const float f2 = fmaf(e[4 * q + 2], bdoi, w.z), f3 = fmaf(e[4 * q + 3], bdoi, w.w);
-        const float p01 = f0 * f1, p23 = f2 * f3, r = fast_rcp(p01 * p23);
-        const float r01 = r * p23, r23 = r * p01;
-        pr[4 * q] = w.x * (r01 * f1);
-        pr[4 * q + 1] = w.y * (r01 * f0);
-        pr[4 * q + 2] = w.z * (r23 * f3);
-        pr[4 * q + 3] = w.w * (r23 * f2);
+        const f2v w01 = {w.x, w.y}, w23 = {w.z, w.w};
+        const f2v f01 = e[2 * q] * bdoi2 + w01, f23 = e[2 * q + 1] * bdoi2 + w23;
+        const f2v pp = f01 * f23;
+        const float r = fast_rcp(pp.x * pp.y);
+        const f2v rp = f2v{r, r} * f2v{pp.y, pp.x};
+        pr[2 * q] = w01 * (rp * f23);
+        pr[2 * q + 1] = w23 * (rp * f01);
         if constexpr (GRAD) {
-#pragma unroll
-          for (int j = 4 * q; j < 4 * q + 4; ++j) E = fmaf(e[j], pr[j], E);
+          E2 += e[2 * q] * pr[2 * q];
+          E2 += e[2 * q + 1] * pr[2 * q + 1];
         }
         if ((same_w >> q) & 1) {              // one logarithm for four classes of one weight (see k_hybrid_loss_tpl)
-          const float w2 = w.x * w.x;
-          S1 = fmaf(w.x, fast_log2((w2 * w2) * r), S1);             // prod_j pr_j = w^4 / (f0 f1 f2 f3) >= 1e-24
+          S1 = fmaf(w.x, fast_log2(w4[q] * r), S1);                 // prod_j pr_j = w^4 / (f0 f1 f2 f3) >= 1e-24
         } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) S1 = fmaf(w[j], fast_log2(pr[4 * q + j]), S1);
+          S1 = fmaf(w.x, fast_log2(pr[2 * q].x), S1);
+          S1 = fmaf(w.y, fast_log2(pr[2 * q].y), S1);
+          S1 = fmaf(w.z, fast_log2(pr[2 * q + 1].x), S1);
+          S1 = fmaf(w.w, fast_log2(pr[2 * q + 1].y), S1);
         }
       }
+      float E = E2.x + E2.y;
       S1 += partner<1>(S1);
       if constexpr (GRAD) E += partner<1>(E);
       S1 = fmaf(sum_boe, fast_log2(zr), S1);
@@ -1253,18 +1280,19 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         const float D = bdo * (A1 - A2 * inv * E);
         const float Cc = w_ce - (D + p0 + pt);
         const float nA2i = -A2 * bdoi, Ci = inv * fmaf(bdo, A1, Cc);
+        const f2v nA2i2 = {nA2i, nA2i}, Ci2 = {Ci, Ci};
 #pragma unroll
-        for (int j = 0; j < HC; ++j) e[j] *= fmaf(nA2i, pr[j], Ci);
+        for (int j = 0; j < HC / 2; ++j) e[j] *= nA2i2 * pr[j] + Ci2;
         g_x0 = fmaf(e_x0, fmaf(nA2i, boe_x0 * rf_x0, Ci), p0 - w_ce);
         g_xt = fmaf(e_xt, fmaf(nA2i, boe_xt * rf_xt, Ci), pt);
         if (x0 == xt) g_x0 = g_xt = g_x0 + pt;
       }
     }
-    D3PM_TL_AFTER(5, e[HC - 1]);
+    D3PM_TL_AFTER(5, e[HC / 2 - 1].y);
     if constexpr (GRAD) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<v4f_nt*>(myhalf + 16 * j) = v4f_nt{e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]};
+        *reinterpret_cast<v4f_nt*>(myhalf + 16 * j) = v4f_nt{e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y};
       if (half == 0) {                        // after both lanes' generic values (LDS executes a wave's writes in order)
         *reinterpret_cast<float*>(tokrow + cls_off(x0)) = g_x0;
         *reinterpret_cast<float*>(tokrow + cls_off(xt)) = g_xt;
@@ -1279,38 +1307,37 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         char* dst = drow + (size_t)base * RB + lane16;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const unsigned q = h * 64 + lane;
-          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16);
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 16 * HS);
           __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(dst + h * 1024));
         }
       } else {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           const unsigned q = h * 64 + lane, r = q / 8, j = q % 8;
-          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(img + (q >> 2) * HS + (q & 3) * 16);
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 16 * HS);
           if (r < nrows)
             __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * RB + j * 16)));
         }
       }
     }
     D3PM_TL(8);
-    if (base + step >= p1) break;             // (uniform over the wave)
+    if (ONE || base + step >= p1) break;      // (uniform over the wave)
     wave_lds_fence();
     issue(base + step);
   }
-  // wave totals without the LDS crossbar: rows of 16 lanes by DPP, the four row totals through scalar registers
-  // (this is the tail of the wave's only pass: its latency is not covered by anything)
+  // Totals: rows of 16 lanes by DPP, the row totals of every wave to LDS, and the first wave adds the (at most) 64
+  // pairs up, again by DPP (this is the tail of the wave's only pass: its latency is not covered by anything, and
+  // every vector instruction here is one of 16 waves').
   acc_vb = group_sum<16>(acc_vb);
   acc_ce = group_sum<16>(acc_ce);
-  acc_vb = (lane_bcast(acc_vb, 0) + lane_bcast(acc_vb, 16)) + (lane_bcast(acc_vb, 32) + lane_bcast(acc_vb, 48));
-  acc_ce = (lane_bcast(acc_ce, 0) + lane_bcast(acc_ce, 16)) + (lane_bcast(acc_ce, 32) + lane_bcast(acc_ce, 48));
-  const int nw = blockDim.x >> 6;
-  if (lane == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
+  if ((lane & 15) == 0) *reinterpret_cast<f2v*>(&red[(wave * 4 + (lane >> 4)) * 2]) = f2v{acc_vb, acc_ce};
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float svb = 0, sce = 0;
-    for (int w = 0; w < nw; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
-    write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
+  if (wave == 0) {
+    const int nrow = (blockDim.x >> 6) * 4;
+    f2v v = {0.0f, 0.0f};
+    if (lane < nrow) v = *reinterpret_cast<const f2v*>(&red[lane * 2]);
+    const float svb = wave_sum(v.x), sce = wave_sum(v.y);
+    if (lane == 0) write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
   }
   D3PM_TL_FLUSH;
 }
@@ -1944,16 +1971,24 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       const long waves = (npos + 31) / 32;
       const int pblock = (int)(waves > 16 ? 16 : waves) * 64;
       const size_t sh = (size_t)(pblock / 64) * 64 * 80;
-      auto go = [&](auto grad, auto next) -> int {
-        auto kern = k_hybrid_loss_pair32<decltype(grad)::value, decltype(next)::value>;
+      // the weights of the two terms in the gradient: grad_scale / (npos ln 2) x {1, 0, hybrid_coeff} by loss type
+      const float cnorm = (float)((double)grad_scale / ((double)npos * 0.6931471805599453));
+      const float w_vb0 = loss_type == D3PM_LOSS_CE ? 0.0f : cnorm;
+      const float w_ce0 = loss_type == D3PM_LOSS_KL ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
+      auto go_one = [&](auto grad, auto next, auto one) -> int {
+        auto kern = k_hybrid_loss_pair32<decltype(grad)::value, decltype(next)::value, decltype(one)::value>;
         if (sh > 48 * 1024) {
           hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
           if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         }
-        hipLaunchKernelGGL(kern, dim3(B), dim3(pblock), sh, s, a, logits, loss_type, hybrid_coeff, grad_scale, grad_out,
-                           o, dlogits, (float)(1.0 / ((double)npos * 0.6931471805599453)), next_q ? *next_q : NextQ{});
+        hipLaunchKernelGGL(kern, dim3(B), dim3(pblock), sh, s, a, logits, loss_type, hybrid_coeff, w_vb0, grad_out,
+                           o, dlogits, w_ce0, next_q ? *next_q : NextQ{});
         D3PM_LAUNCH_CHECK("k_hybrid_loss_pair32");
         return D3PM_OK;
+      };
+      // one pass: the workgroup's waves cover the element (pblock / 2 tokens), every wave has tokens
+      auto go = [&](auto grad, auto next) -> int {
+        return 2 * npos <= pblock ? go_one(grad, next, std::true_type{}) : go_one(grad, next, std::false_type{});
       };
       if (next_q && dlogits && npos <= pblock) {      // the launch that also corrupts the next batch
         *next_done = true;

@@ -92,6 +92,7 @@ __device__ __forceinline__ void store_slots_off(char* __restrict__ base, unsigne
 // (dirty lines left in the XCDs' L2 are written back only when the kernel ends; streamed out, that traffic
 // overlaps the kernel's own run time).
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));      // a pair of classes: arithmetic on it maps onto v_pk_*_f32
 template <class L>
 __device__ __forceinline__ void store_slots_off_nt(char* __restrict__ base, unsigned row_off, int g, int K,
                                                    const float (&z)[L::V]) {
