@@ -425,15 +425,28 @@ __global__ __launch_bounds__(64) void k_lvb_digest32(d3pm_tables_f64 tb, float* 
 // slot's generic terms are those of a class of zero probability (taken out again with the same expressions, bit for
 // bit), and the gradient loop leaves a zero in the slot, over which the token's own value for x0 is stored.
 // cs = grad_scale / npos, ces = ce_grad_scale / npos from the host.
-struct LvbGeneric { float qv, tj, d; };
-__device__ __forceinline__ LvbGeneric lvb_generic(float e2, float mo, float c3, float k1, float nc3) {
+// T = float for one class, f2v for a pair of classes (the class loops run on pairs: packed float32 instructions,
+// one issue slot for two classes).
+__device__ __forceinline__ float rcp_each(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ f2v rcp_each(f2v v) { return f2v{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+__device__ __forceinline__ f2v exp2_each(f2v v) { return f2v{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ f2v both(float v) { return f2v{v, v}; }
+__device__ __forceinline__ f2v log2_1p(f2v d) {          // log2_1p(float) on both halves
+  d = f2v{fmaxf(d.x, -0.99999994f), fmaxf(d.y, -0.99999994f)};
+  const f2v w = d + both(1.0f);
+  const f2v lw = {__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)};
+  return (d - (w - both(1.0f))) * both(1.44269504088896340736f) + lw;
+}
+template <class T> struct LvbGeneric { T qv, tj, d; };
+template <class T>
+__device__ __forceinline__ LvbGeneric<T> lvb_generic(T e2, T mo, T c3, T k1, T nc3) {
   // s'_j = mo_j + c3 e_j^2;  qv = mo_j / s'_j;  tj = e_j^2 / s'_j (so that qv + c3 tj = 1);
   // d_j = post_j / P_j - 1 = qv (rs - den) / den - c3 tj: both parts without cancellation
-  const float r = __builtin_amdgcn_rcpf(fmaf(e2, c3, mo));
-  LvbGeneric g;
+  const T r = rcp_each(e2 * c3 + mo);
+  LvbGeneric<T> g;
   g.qv = mo * r;
   g.tj = e2 * r;
-  g.d = fmaf(g.qv, k1, g.tj * nc3);
+  g.d = g.qv * k1 + g.tj * nc3;
   return g;
 }
 
@@ -447,10 +460,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.693147180559945309417f;
   constexpr int TR = MSA ? 9 : 5;                           // rows of the digest indexed by a token's classes
   extern __shared__ __align__(16) char lvb_rows[];          // [waves][64][STRIDE]
-  __shared__ double red[HYB ? 16 : 8];
+  static_assert(K % 2 == 0 && LD % 2 == 0, "classes are taken in pairs");
+  constexpr int KP = K / 2, LP = LD / 2;
+  __shared__ double red[HYB ? 64 : 32];                     // the sums of every 16-lane row of every wave
   __shared__ float s_tab[8][TR][32];                        // a copy per wave: no workgroup barrier
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index through the scalar unit: what derives from it is scalar arithmetic and scalar branches)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
   const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
   const char* __restrict__ prow = (const char*)(pred + (size_t)b * a.npos * LD);
@@ -474,7 +490,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   const int t0 = (int)a.t[b];
   const int t = (t0 == tmax) ? t0 : lvb_timestep(t0, a.tb.T);
   const int branch = (t == 1) ? 0 : (t == tmax ? 1 : 2);
-  float mo[K];
+  f2v mo[KP];
   float mdo = 0, sum_mo = 0;
   if (branch == 2) {
     // (t is uniform over the workgroup: these are scalar loads)
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
       for (int r = 0; r < TR; ++r) s_tab[wave][r][lane] = dg[r * 32 + lane];
     }
 #pragma unroll
-    for (int j = 0; j < K; ++j) mo[j] = dg[2 * 32 + j];
+    for (int j = 0; j < KP; ++j) mo[j] = f2v{dg[2 * 32 + 2 * j], dg[2 * 32 + 2 * j + 1]};
     mdo = dg[9 * 32];
     sum_mo = dg[9 * 32 + 1];
   }
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const bool live = base + lane < p1;
     x0 = clamp_index(x0, K);                                 // out-of-range tokens are clamped: nothing faults
     xt = clamp_index(xt, K);
-    float e[LD];
+    f2v e[LP];                                               // the lane's row as pairs of classes
     float tok_loss = 0, tok_ce = 0, set0 = 0, addt = 0;
     bool set_x0 = false;                                     // (uniform) the x0 slot is stored, not added to
     auto from_q = [&]() {
@@ -516,38 +532,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
       if (branch != 2) {
         // CrossEntropyLoss over all LD logits: the loss of an element at t == 1 (losses.py:54) and the driver's
         // second term (every element)
-        Img::read_row(img, lane, e);
-        float m = e[0];
+        Img::read_row_pairs(img, lane, e);
+        float m = fmaxf(e[0].x, e[0].y);
 #pragma unroll
-        for (int j = 1; j < LD; ++j) m = fmaxf(m, e[j]);
+        for (int j = 1; j < LP; ++j) m = fmaxf(fmaxf(m, e[j].x), e[j].y);
         const float mneg = -m * LOG2E;
-        float s = 0;
+        f2v s2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < LD; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg)); s += e[j]; }
+        for (int j = 0; j < LP; ++j) { e[j] = exp2_each(e[j] * both(LOG2E) + both(mneg)); s2 += e[j]; }
+        const float s = s2.x + s2.y;
         tok_ce = fmaf(__builtin_amdgcn_logf(s), LN2, m - z_x0);
         tok_loss = branch == 0 ? tok_ce : 0.0f;                // (t == tmax: the element's term went to acc above)
         const float w = (branch == 0 ? cs : 0.0f) + ces;
         const float wi = w * __builtin_amdgcn_rcpf(s);
 #pragma unroll
-        for (int j = 0; j < LD; ++j) e[j] *= wi;
+        for (int j = 0; j < LP; ++j) e[j] *= both(wi);
         set0 = -w;                                             // (added to the slot: set_x0 stays false)
       } else {
         const float z_xt = *reinterpret_cast<const float*>(myrow + 4 * xt);
         *reinterpret_cast<float*>(myrow + 4 * x0) = -INFINITY;  // after both reads (a wave's LDS operations are in order)
         wave_lds_order();
-        Img::read_row(img, lane, e);
-        float m = e[0];
+        Img::read_row_pairs(img, lane, e);
+        float m = fmaxf(e[0].x, e[0].y);
 #pragma unroll
-        for (int j = 1; j < K; ++j) m = fmaxf(m, e[j]);
+        for (int j = 1; j < KP; ++j) m = fmaxf(fmaxf(m, e[j].x), e[j].y);
         m = fmaxf(m, z_x0);
         const float mneg = -m * LOG2E;
-        float s = 0, R0 = 0;                                   // R0 = sum of e_j^2 over the classes other than x0
+        f2v s2 = {0.0f, 0.0f}, R2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg));
-          s += e[j];
-          R0 = fmaf(e[j], e[j], R0);
+        for (int j = 0; j < KP; ++j) {
+          e[j] = exp2_each(e[j] * both(LOG2E) + both(mneg));
+          s2 += e[j];
+          R2 = e[j] * e[j] + R2;
         }
+        float s = s2.x + s2.y;
+        const float R0 = R2.x + R2.y;                          // sum of e_j^2 over the classes other than x0
         const float e_x0 = __builtin_amdgcn_exp2f(fmaf(z_x0, LOG2E, mneg)), e_xt = __builtin_amdgcn_exp2f(fmaf(z_xt, LOG2E, mneg));
         s += e_x0;
         const float ee_x0 = e_x0 * e_x0, ee_xt = e_xt * e_xt;
@@ -572,18 +591,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // logarithm of the rounded ratio (6e-8 absolute) would leave an error of that size in a sum that can be
         // far smaller.
         const float Dl = same_b ? -da * w1 : da * w2, k1 = Dl * iden;
-        float qv[K], G1 = 0, Hq = 0, Hp = 0;
+        f2v qv[KP], G2 = {0.0f, 0.0f}, Hq2 = {0.0f, 0.0f}, Hp2 = {0.0f, 0.0f};
         // (One logarithm for several classes of equal weight, as the image kernel takes it, does not carry over: a
         // product of the ratios kept as 1 + D loses the factor's relative accuracy wherever a ratio is far below
         // one (early timesteps), and kept as a plain product it is rounded against one (late timesteps).)
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const LvbGeneric g = lvb_generic(e[j] * e[j], mo[j], c3, k1, nc3);
+        for (int j = 0; j < KP; ++j) {
+          const LvbGeneric<f2v> g = lvb_generic(e[j] * e[j], mo[j], both(c3), both(k1), both(nc3));
           qv[j] = g.qv;
-          G1 = fmaf(mo[j], log2_1p(g.d), G1);
-          Hq = fmaf(mo[j], g.qv, Hq);
-          Hp = fmaf(mo[j], g.tj, Hp);                                 // sum_j e_j^2 qv_j
+          G2 = mo[j] * log2_1p(g.d) + G2;
+          Hq2 = mo[j] * g.qv + Hq2;
+          Hp2 = mo[j] * g.tj + Hp2;                                   // sum_j e_j^2 qv_j
         }
+        const float G1 = G2.x + G2.y, Hq = Hq2.x + Hq2.y, Hp = Hp2.x + Hp2.y;
         // special classes: x0 has B = mo + mdo, x_t has A = a_diag (both at once when x0 == x_t)
         const float r_x0 = __builtin_amdgcn_rcpf(sp_x0), r_xt = __builtin_amdgcn_rcpf(sp_xt);
         const float b_x0 = mo_x0 + mdo, a_x0 = fmaf(same, da, a_o);
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // without cancellation:
         //   x0 == x_t:  d0 = w1 Sm / (s'_x0 den)
         //   otherwise:  d0 = (w1 den + da w2 b_x0) / (s'_x0 den),   dt = -w2 Sm / (s'_xt den)
-        const LvbGeneric g0s = lvb_generic(0.0f, mo_x0, c3, k1, nc3);
+        const LvbGeneric<float> g0s = lvb_generic(0.0f, mo_x0, c3, k1, nc3);
         const float lg_x0 = log2_1p(g0s.d);
         const float d0r = (same_b ? w1 * Sm : fmaf(w1, den, da * w2 * b_x0)) * r_x0 * iden;
         const float dtr = -w2 * Sm * r_xt * iden;
@@ -630,32 +650,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
           // softmax over all LD logits from the K exponentials at hand: softmax_j = e_j f / S_all
           float S_all = s, f = 1.0f, m_all = m;
           if constexpr (LD > K) {
-            float mx = e[K];
+            float mx = fmaxf(e[KP].x, e[KP].y);
 #pragma unroll
-            for (int j = K + 1; j < LD; ++j) mx = fmaxf(mx, e[j]);
+            for (int j = KP + 1; j < LP; ++j) mx = fmaxf(fmaxf(mx, e[j].x), e[j].y);
             m_all = fmaxf(m, mx);
             const float mneg_all = -m_all * LOG2E;
             f = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, mneg_all));
             S_all = s * f;
 #pragma unroll
-            for (int j = K; j < LD; ++j) { e[j] = __builtin_amdgcn_exp2f(fmaf(e[j], LOG2E, mneg_all)); S_all += e[j]; }
+            for (int j = KP; j < LP; ++j) {
+              e[j] = exp2_each(e[j] * both(LOG2E) + both(mneg_all));
+              S_all += e[j].x + e[j].y;
+            }
           }
           tok_ce = fmaf(__builtin_amdgcn_logf(S_all), LN2, m_all - z_x0);
           const float wi = ces * __builtin_amdgcn_rcpf(S_all);
           c6 = fmaf(-wi, f, c6);
           ce_x0 = -ces;
 #pragma unroll
-          for (int j = K; j < LD; ++j) e[j] *= wi;
+          for (int j = KP; j < LP; ++j) e[j] *= both(wi);
         } else {
 #pragma unroll
-          for (int j = K; j < LD; ++j) e[j] = 0.0f;
+          for (int j = KP; j < LP; ++j) e[j] = both(0.0f);
         }
         // the token's own value for x0 (stored over the loop's zero) and the extra of x_t (added)
         set0 = fmaf(2.0f * pp_x0, fmaf(mdo, gx0, W), fmaf(-c6, e_x0, ce_x0));
         addt = 2.0f * pp_xt * mdo * dt;
         set_x0 = true;
 #pragma unroll
-        for (int j = 0; j < K; ++j) e[j] *= fmaf(e[j], fmaf(-c5, qv[j], c4), -c6);
+        for (int j = 0; j < KP; ++j) e[j] *= e[j] * (qv[j] * both(-c5) + both(c4)) + both(-c6);
       }
       acc += live ? (double)tok_loss : 0.0;
       if constexpr (HYB) acc_ce += live ? (double)tok_ce : 0.0;
@@ -667,13 +690,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
       if (branch == 1) {
         from_q();
 #pragma unroll
-        for (int j = 0; j < LD; ++j) e[j] = 0.0f;
+        for (int j = 0; j < LP; ++j) e[j] = both(0.0f);
       } else {
         from_rows();
       }
     }
     // gradient rows back through the image; the special classes are patched in the lane's own row
-    Img::write_row(img, lane, e);
+    Img::write_row_pairs(img, lane, e);
     if (set_x0) *reinterpret_cast<float*>(myrow + 4 * x0) = set0;
     else *reinterpret_cast<float*>(myrow + 4 * x0) += set0;
     *reinterpret_cast<float*>(myrow + 4 * xt) += addt;
@@ -687,19 +710,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // 6.86 against 6.60 us at B = 256; held to 168 registers that variant spills, 59 us)
     issue(base + blockDim.x);
   }
-  acc = wave_sum(acc);
-  if constexpr (HYB) acc_ce = wave_sum(acc_ce);
-  if (lane == 0) {
-    red[wave] = acc;
-    if constexpr (HYB) red[8 + wave] = acc_ce;
+  // Totals: rows of 16 lanes by DPP, every wave's four row totals to LDS, and the first wave adds the (at most 32)
+  // of them up -- two reduction steps less on every wave, on the tail of its last pass.
+  acc = group_sum<16>(acc);
+  if constexpr (HYB) acc_ce = group_sum<16>(acc_ce);
+  if ((lane & 15) == 0) {
+    red[wave * 4 + (lane >> 4)] = acc;
+    if constexpr (HYB) red[32 + wave * 4 + (lane >> 4)] = acc_ce;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double sacc = 0, sce = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-      sacc += red[w];
-      if constexpr (HYB) sce += red[8 + w];
+  if (wave == 0) {
+    const int nrow = (int)(blockDim.x >> 6) * 4;
+    double sacc = lane < nrow ? red[lane] : 0.0, sce = 0;
+    sacc = group_sum<32>(sacc);
+    if constexpr (HYB) {
+      sce = lane < nrow ? red[32 + lane] : 0.0;
+      sce = group_sum<32>(sce);
     }
+    if (lane != 0) return;
     if (a.chunks == 1) per_seq[b] = sacc / (double)a.npos;
     else part[(size_t)b * a.chunks + chunk] = sacc;
     if constexpr (HYB) {

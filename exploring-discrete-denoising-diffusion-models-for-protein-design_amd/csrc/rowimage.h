@@ -64,22 +64,26 @@ struct RowImage {
         stage[h] = *reinterpret_cast<const piece_t*>(first + min((unsigned)(h * 64 + lane) * PB, limit));
     }
   }
-  // Image row of piece 64 h + lane, from the lane's own quotient and remainder by PIECES (taken once).
-  struct LaneSplit { unsigned row, col; };
+  // Where piece 64 h + lane of the wave's block lies in the image: byte (64 h + lane) PB plus the padding of the rows
+  // before it, (64 h + lane) / PIECES of them.  With 64 h = QH PIECES + RH that quotient is lane / PIECES + QH, plus
+  // one where lane % PIECES + RH carries: the lane keeps its own byte offset with and without the carry for each
+  // distinct RH (equal expressions: one register each), and everything that depends on h is a constant.
+  struct LaneSplit { unsigned row, col, at; };
   __device__ static __forceinline__ LaneSplit split(int lane) {
-    return LaneSplit{(unsigned)lane / PIECES, (unsigned)lane % PIECES};
+    const unsigned row = (unsigned)lane / PIECES, col = (unsigned)lane % PIECES;
+    return LaneSplit{row, col, (unsigned)lane * PB + row * (STRIDE - RB)};
+  }
+  __device__ static __forceinline__ unsigned piece_at(LaneSplit ls, int h) {
+    const unsigned QH = (64u * h) / PIECES, RH = (64u * h) % PIECES;     // constants once unrolled
+    unsigned at = ls.at + 64u * h * PB + QH * (STRIDE - RB);
+    if (RH != 0) at += (ls.col >= (unsigned)PIECES - RH) ? (unsigned)(STRIDE - RB) : 0u;
+    return at;
   }
   __device__ __forceinline__ void deposit_flat(char* img, int lane, LaneSplit ls) const {
 #pragma unroll
     for (int h = 0; h < PIECES; ++h) {
-      const unsigned q = h * 64 + lane;
-      if constexpr (STRIDE == RB) {
-        *reinterpret_cast<piece_t*>(img + q * PB) = stage[h];
-      } else {
-        const unsigned QH = (64u * h) / PIECES, RH = (64u * h) % PIECES;   // constants once unrolled
-        const unsigned row = ls.row + QH + ((ls.col + RH >= (unsigned)PIECES) ? 1u : 0u);
-        *reinterpret_cast<piece_t*>(img + q * PB + row * (STRIDE - RB)) = stage[h];
-      }
+      if constexpr (STRIDE == RB) *reinterpret_cast<piece_t*>(img + (unsigned)(h * 64 + lane) * PB) = stage[h];
+      else *reinterpret_cast<piece_t*>(img + piece_at(ls, h)) = stage[h];
     }
   }
   // The requested pieces into the image.
@@ -108,19 +112,42 @@ struct RowImage {
         *reinterpret_cast<piece_t*>(img + lane * STRIDE + j * PB) = piece_t{z[2 * j], z[2 * j + 1]};
     }
   }
+  // The same with the row as LD / 2 pairs of neighbouring elements (arithmetic on pairs maps onto packed float32).
+  __device__ static __forceinline__ void read_row_pairs(const char* img, int lane, f2v (&z)[LD / 2]) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const piece_t q = *reinterpret_cast<const piece_t*>(img + lane * STRIDE + j * PB);
+      if constexpr (PB == 16) { z[2 * j] = f2v{q.x, q.y}; z[2 * j + 1] = f2v{q.z, q.w}; }
+      else z[j] = f2v{q.x, q.y};
+    }
+  }
+  __device__ static __forceinline__ void write_row_pairs(char* img, int lane, const f2v (&z)[LD / 2]) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      if constexpr (PB == 16)
+        *reinterpret_cast<piece_t*>(img + lane * STRIDE + j * PB) = piece_t{z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y};
+      else
+        *reinterpret_cast<piece_t*>(img + lane * STRIDE + j * PB) = piece_t{z[j].x, z[j].y};
+    }
+  }
   // The image's first `nrows` rows to a contiguous block of rows starting at `first`, addressed as in request_flat.
   __device__ static __forceinline__ void store_flat(const char* img, char* __restrict__ first, unsigned nrows, int lane,
                                                     LaneSplit ls) {
+    if (nrows >= 64) {                        // (uniform over the wave) every piece exists
 #pragma unroll
-    for (int h = 0; h < PIECES; ++h) {
-      const unsigned q = h * 64 + lane;
-      unsigned at = q * PB;
-      if constexpr (STRIDE != RB) {
-        const unsigned QH = (64u * h) / PIECES, RH = (64u * h) % PIECES;   // constants once unrolled
-        at += (ls.row + QH + ((ls.col + RH >= (unsigned)PIECES) ? 1u : 0u)) * (STRIDE - RB);
+      for (int h = 0; h < PIECES; ++h) {
+        const unsigned q = h * 64 + lane;
+        const unsigned at = (STRIDE != RB) ? piece_at(ls, h) : q * PB;
+        __builtin_nontemporal_store(*reinterpret_cast<const piece_t*>(img + at), reinterpret_cast<piece_t*>(first + q * PB));
       }
-      const piece_t v = *reinterpret_cast<const piece_t*>(img + at);
-      if (q * PB < nrows * RB) __builtin_nontemporal_store(v, reinterpret_cast<piece_t*>(first + q * PB));
+    } else {
+#pragma unroll
+      for (int h = 0; h < PIECES; ++h) {
+        const unsigned q = h * 64 + lane;
+        const unsigned at = (STRIDE != RB) ? piece_at(ls, h) : q * PB;
+        const piece_t v = *reinterpret_cast<const piece_t*>(img + at);
+        if (q * PB < nrows * RB) __builtin_nontemporal_store(v, reinterpret_cast<piece_t*>(first + q * PB));
+      }
     }
   }
   // The image's first `nrows` rows to global memory, coalesced, non-temporal (a streamed output).
