@@ -734,7 +734,7 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
   __shared__ float s_tab[MAX_WAVES][3][32];
   const float eps = a.tb.eps;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
   const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
   const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * KC);

@@ -505,6 +505,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     sum_mo = dg[9 * 32 + 1];
   }
   double acc = 0, acc_ce = 0;
+  if (branch == 1) {
+    // (uniform, one element in T) KL(q || uniform) on the collater's forward probabilities (losses.py:58-60), no
+    // gradient.  A loop of its own: inside the main loop the compiler hoists this path's double-precision constants
+    // and its division in front of the loop, where every wave of every element pays for them.
+    for (unsigned bq = pbeg + wave * 64; bq < p1; bq += blockDim.x) {
+      if (bq + lane >= p1) continue;
+      if (!q) { acc = (double)NAN; continue; }               // no probabilities given: NaN, nothing is read
+      const double* qq = q + ((size_t)b * a.npos + bq + lane) * K;
+      double s = 0;
+      for (int j = 0; j < K; ++j) s += (qq[j] > 0.0 ? qq[j] * log(qq[j]) : 0.0) - qq[j] * log_prior;
+      // 'batchmean' divides by the leading size of q[i]: L for a sequence (the final division), but only the
+      // depth D for an MSA laid out [D,L,K]
+      acc += s * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
+    }
+  }
   for (;; base += blockDim.x) {
     if (base >= p1) break;                                   // (uniform over the wave)
     const bool live = base + lane < p1;
@@ -513,18 +528,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     f2v e[LP];                                               // the lane's row as pairs of classes
     float tok_loss = 0, tok_ce = 0, set0 = 0, addt = 0;
     bool set_x0 = false;                                     // (uniform) the x0 slot is stored, not added to
-    auto from_q = [&]() {
-      // KL(q || uniform) on the collater's forward probabilities (losses.py:58-60); no gradient
-      if (live && !q) acc = (double)NAN;                       // no probabilities given: NaN, nothing is read
-      if (live && q) {
-        const double* qq = q + ((size_t)b * a.npos + base + lane) * K;
-        double s = 0;
-        for (int j = 0; j < K; ++j) s += (qq[j] > 0.0 ? qq[j] * log(qq[j]) : 0.0) - qq[j] * log_prior;
-        // 'batchmean' divides by the leading size of q[i]: L for a sequence (the final division), but only the
-        // depth D for an MSA laid out [D,L,K]
-        acc += s * (msa > 0 ? (double)a.npos / (double)msa : 1.0);
-      }
-    };
     auto from_rows = [&]() {
       rows.deposit_flat(img, lane, ls);
       wave_lds_order();
@@ -684,11 +687,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
       if constexpr (HYB) acc_ce += live ? (double)tok_ce : 0.0;
     };
     if constexpr (HYB) {
-      if (branch == 1) from_q();
       from_rows();
     } else {
       if (branch == 1) {
-        from_q();
 #pragma unroll
         for (int j = 0; j < LP; ++j) e[j] = both(0.0f);
       } else {
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(512) void k_lvb_reverse_tpl(ProtArgs a, const float
   __shared__ float s_tab[8][3][32];                         // per wave: a_diag, a_off of Q_t by x_t; mo by class
   if (offset_dev) offset += *offset_dev;
   const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
   const unsigned pbeg = (unsigned)(chunk * a.chunk_pos);
   const char* __restrict__ prow = (const char*)(pred + (size_t)b * a.npos * LD);
