@@ -49,6 +49,10 @@ TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_kernels_pmc_hb
 TRACE_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_roofline_kernel_stats.csv",)]
 
 
+# the headline kernel: gradient, no next-batch corruption, one pass (the workgroup covers its batch element)
+HEAD_KERNEL = "k_hybrid_loss_pair32<true, false, true>"
+
+
 def measured_traffic(kernel: str, must_contain: str = ""):
     for path in TRAFFIC_FILES:
         try:
@@ -388,11 +392,11 @@ def worker(args):
 
     if args.roofline_only:
         # exactly the launch sequence roofline.frac is quoted on, and nothing else of this kernel: the program of the
-        # rocprofv3 kernel trace kept under profiles/ (its average duration of k_hybrid_loss_pair32<true, false> is
+        # rocprofv3 kernel trace kept under profiles/ (its average duration of k_hybrid_loss_pair32<true, false, true> is
         # this figure as the tracer sees it)
         ms = fused_kernel_ms(d, nsets=10)
         ach = BYTES_PER_TOKEN * B * L / (ms * 1e-3) / 1e9
-        print(json.dumps({"roofline_only": True, "kernel": "k_hybrid_loss_pair32<true, false>", "kernel_ms": ms,
+        print(json.dumps({"roofline_only": True, "kernel": HEAD_KERNEL, "kernel_ms": ms,
                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                           "launches": "10 rotating buffer sets, back to back between two HIP events, median of 5 blocks"}),
               flush=True)
@@ -768,7 +772,7 @@ def worker(args):
                             "frac": l_ach / HBM_PEAK_GBS, "kernel": "k_lvb_loss_tpl<22, 24, false, true> via "
                             "d3pm_lvb_hybrid_loss, back-to-back launches between two HIP events", "kernel_ms": lk_ms,
                             "kernel_ms_lvb_alone": lo_ms, "algorithmic_bytes_per_token": lbytes,
-                            "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false")}}
+                            "traffic": measured_traffic("k_lvb_loss_tpl<22, 24, false, true>")}}
 
     # ---- secondary: the two loss kernels at eight times the batch (B = 2048: the global batch of the DDP
     # configuration on one GPU; 285 / 218 MB per launch, more than the 256 MiB Infinity Cache holds), where launch
@@ -828,12 +832,12 @@ def worker(args):
         # HBM proper); the same launch on one 35.7 MB working set, which the 256 MiB Infinity Cache serves, is kept
         # beside it as *_cache_resident
         achieved = BYTES_PER_TOKEN * B * L / (kern_rot_ms * 1e-3) / 1e9
-        traffic = measured_traffic("k_hybrid_loss_pair32<true, false>")
+        traffic = measured_traffic(HEAD_KERNEL)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": (traffic["source"] + " (a committed rocprofv3 --pmc pass of this command, not "
                                    "measured by this run)") if traffic else None,
-                "kernel": "k_hybrid_loss_pair32<true, false> via d3pm_hybrid_loss, back-to-back launches over 10 "
+                "kernel": HEAD_KERNEL + " via d3pm_hybrid_loss, back-to-back launches over 10 "
                           "rotating sets of inputs and outputs between two HIP events",
                 "kernel_ms": kern_rot_ms, "algorithmic_bytes_per_token": BYTES_PER_TOKEN,
                 "tokens_per_launch": B * L,
@@ -843,7 +847,7 @@ def worker(args):
                         "*_cache_resident: one 35.7 MB working set relaunched back to back, which stays in the "
                         "256 MiB Infinity Cache; `bench.py --roofline-only` launches exactly the rotating sequence "
                         "(the program of the committed rocprofv3 kernel trace)"}
-        traced = traced_duration_ms("k_hybrid_loss_pair32<true, false>")
+        traced = traced_duration_ms(HEAD_KERNEL)
         if traced:
             # the tracer serialises the dispatches and brackets each with its own packets: a kernel of this size
             # reads 0.4-0.5 us longer under it than its back-to-back rate, which is what the events (and the wall
@@ -858,7 +862,7 @@ def worker(args):
             roof["frac_graph_replayed"] = BYTES_PER_TOKEN * B * L / (kern_replayed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if kern_next_ms:
             # the launch the pipelined step actually makes: the same kernel carrying the next batch's timestep draw
-            # and corruption (k_hybrid_loss_pair32<true, true>): 16 more bytes per token
+            # and corruption (k_hybrid_loss_pair32<true, true, true>): 16 more bytes per token
             roof["kernel_ms_with_next_q_sample"] = kern_next_ms
             roof["frac_with_next_q_sample"] = (BYTES_PER_TOKEN + 16) * B * L / (kern_next_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {

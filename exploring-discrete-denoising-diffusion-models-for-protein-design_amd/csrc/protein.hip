@@ -705,10 +705,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     Img::store_flat(img, drow + (size_t)base * Img::RB, min(64u, p1 - base), lane, ls);
     if (base + blockDim.x >= p1) break;
     wave_lds_order();
-    // (the next pass's rows are requested here, where the pass's registers are free: requested right after the
-    // deposit instead they travel while the pass computes, but hold 26 more registers through it -- 200 against
-    // 168, two waves per SIMD against three in the 256-thread launches: 39.5 against 41.3 us at B = 2048 and
-    // 6.86 against 6.60 us at B = 256; held to 168 registers that variant spills, 59 us)
+    // (the next pass's rows are requested here, where the pass's registers are free.  Requested right after the
+    // deposit instead they travel while the pass computes and hold 26 more registers through it: 142 -> 168, still
+    // three waves per SIMD, measured 36.4 against 36.9 us at B = 2048 and 6.6 against 6.45 us with the
+    // cross-entropy term at B = 256 -- the large launch runs at what the memory system gives a mixed read / write
+    // stream either way, so the simpler order stays.  Held to 128 registers for a fourth wave the kernel spills
+    // 10 of them: 42.6 us.)
     issue(base + blockDim.x);
   }
   // Totals: rows of 16 lanes by DPP, every wave's four row totals to LDS, and the first wave adds the (at most 32)
