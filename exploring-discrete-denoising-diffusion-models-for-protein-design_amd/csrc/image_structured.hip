@@ -989,7 +989,7 @@ __global__ __launch_bounds__(MAXT) void k_hybrid_loss_tpl(
 // which is what the vector ALUs need to issue back to back, and a finer pipeline of load / compute / store phases
 // over the chip.  The price: the per-token scalar work runs on both lanes, the per-class constants are per lane
 // (vector registers) and four sums per token cross the pair (one DPP operation each).  The LDS image holds the
-// wave's 64 half-rows at a stride of 80 bytes (odd multiple of 16).
+// wave's 32 rows at a stride of 144 bytes (an odd number of 16-byte slots), a lane's half at byte 64 h of its row.
 // NEXT: the launch also draws the timesteps and the noisy tokens of the NEXT batch (what d3pm_q_sample_draw_t
 // does, same Philox stream, same result) while its own rows are still on their way from memory: a training loop
 // whose batches are staged ahead then needs one launch per step instead of two.  The first wave builds the
@@ -1010,8 +1010,8 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float w_ce0, NextQ nx) {
   // w_vb0 / w_ce0: the weights of the two loss terms in the gradient, grad_scale / (npos ln 2) times 1, 0 or the
   // hybrid coefficient as the loss type says, formed on the host: the kernel runs its set-up once per wave of 32 tokens
-  constexpr int KC = 32, HC = 16, RB = 4 * KC, HS = 4 * HC + 16, PW = 16;     // PW: waves per workgroup at most
-  extern __shared__ __align__(16) char pair_rows[];         // [waves][64 half-rows][HS]
+  constexpr int KC = 32, HC = 16, RB = 4 * KC, TS = RB + 16, PW = 16;         // PW: waves per workgroup at most
+  extern __shared__ __align__(16) char pair_rows[];         // [waves][32 rows][TS]
   __shared__ __align__(8) float red[PW * 4 * 2];            // (vb, ce) of each 16-lane row of each wave
   __shared__ __align__(16) float s_tab[PW][3][KC];          // as in k_hybrid_loss_tpl: a copy per wave
   __shared__ __align__(16) float s_w4[PW][KC / 4];          // (off + eps)^4 of the first class of every group of four
@@ -1028,13 +1028,15 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   const char* __restrict__ x0row = (const char*)a.x0 + (size_t)b * a.npos * a.x0_bytes;
   const char* __restrict__ xtrow = (const char*)a.xt + (size_t)b * a.npos * a.xt_bytes;
   const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
-  char* const img = pair_rows + (size_t)wave * 64 * HS;
-  char* const myhalf = img + lane * HS;                     // half-row index = lane
-  // piece h of this lane in the wave's block of rows (16 bytes at byte 1024 h + 16 lane of it) belongs to half-row
-  // 16 h + lane / 4, 16-byte piece lane % 4 of it
-  char* const piece0 = img + (lane >> 2) * HS + (lane & 3) * 16;
-  char* const tokrow = img + (lane & ~1) * HS;              // class c of this token: tokrow + (c >> 4) * HS + 4 * (c & 15)
-  auto cls_off = [](int c) { return (c >> 4) * HS + 4 * (c & 15); };
+  // The wave's image: 32 rows of 128 bytes at a stride of 144 (nine 16-byte slots: the 8 lanes of an access group,
+  // four tokens' two halves, 9 p + 4 h + j, fall on eight different slots), a lane's half at byte 64 h of its row.
+  char* const img = pair_rows + (size_t)wave * 32 * TS;
+  char* const tokrow = img + ptok * TS;                     // class c of this token: tokrow + 4 c
+  char* const myhalf = tokrow + 64 * half;
+  // piece h of this lane in the wave's block of rows (16 bytes at byte 1024 h + 16 lane of it) belongs to row
+  // 8 h + lane / 8, 16-byte piece lane % 8 of it
+  char* const piece0 = img + (lane >> 3) * TS + (lane & 7) * 16;
+  auto cls_off = [](int c) { return 4 * c; };
 
   if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
 
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
     float m = 0, inv = 0, l2s = 0, mneg = 0;
     if (work) {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) *reinterpret_cast<v4f_nt*>(piece0 + h * 16 * HS) = stage[h];
+      for (int h = 0; h < 4; ++h) *reinterpret_cast<v4f_nt*>(piece0 + h * 8 * TS) = stage[h];
       if (first && need_post && lane < KC) {
         // this wave's table copy goes to LDS together with the rows (the digest values were requested right behind
         // the rows and arrive with them): the fence below covers both, and nothing waits on LDS after phase A
@@ -1307,14 +1309,14 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
         char* dst = drow + (size_t)base * RB + lane16;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 16 * HS);
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 8 * TS);
           __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(dst + h * 1024));
         }
       } else {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           const unsigned q = h * 64 + lane, r = q / 8, j = q % 8;
-          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 16 * HS);
+          const v4f_nt v = *reinterpret_cast<const v4f_nt*>(piece0 + h * 8 * TS);
           if (r < nrows)
             __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(drow + ((base + r) * RB + j * 16)));
         }
@@ -1970,7 +1972,7 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       // two lanes per token: 32 tokens per wave, up to 16 waves per workgroup
       const long waves = (npos + 31) / 32;
       const int pblock = (int)(waves > 16 ? 16 : waves) * 64;
-      const size_t sh = (size_t)(pblock / 64) * 64 * 80;
+      const size_t sh = (size_t)(pblock / 64) * 32 * 144;    // a wave's image: 32 rows at a stride of 144 bytes
       // the weights of the two terms in the gradient: grad_scale / (npos ln 2) x {1, 0, hybrid_coeff} by loss type
       const float cnorm = (float)((double)grad_scale / ((double)npos * 0.6931471805599453));
       const float w_vb0 = loss_type == D3PM_LOSS_CE ? 0.0f : cnorm;

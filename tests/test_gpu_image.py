@@ -307,6 +307,12 @@ def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
         close(vb + lam * ce, loss_ref.detach().numpy(), atol=1e-6, what=f"vb + lam ce {kind} K={K}")
         ref = logits.grad.numpy()
         close(dl, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {kind} K={K}")
+        # forward only (no gradient asked for): the kernels' other variant, same losses
+        loss_f = torch.empty(B, device=DEV)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0d), 8, ptr(xtd), 8, ptr(td), 4, B, npos, LOSS["hybrid"],
+                                   lam, 1.0, None, None, None, ptr(loss_f), None, None, None, 0, ptr(ws), wsb,
+                                   stream_ptr()))
+        close(loss_f, loss_ref.detach().numpy(), atol=1e-6, what=f"forward-only loss {kind} K={K}")
 
 
 @pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
@@ -865,7 +871,7 @@ def test_training_step_several_steps_per_graph(pkg):
 
 
 @pytest.mark.parametrize("kind,bits,B,L", [("uniform", 5, 256, 512), ("absorbing", 5, 200, 96), ("uniform", 5, 64, 48),
-                                            ("uniform", 4, 256, 128), ("gaussian", 4, 5, 40)])
+                                            ("uniform", 4, 256, 128), ("gaussian", 4, 5, 40), ("uniform", 5, 192, 700)])
 def test_pipelined_steps_equal_unpipelined(pkg, kind, bits, B, L):
     """A graph whose loss launch of step i also draws the timesteps and noisy tokens of step i + 1
     (d3pm_hybrid_loss_then_q_sample: one launch at K = 32 with a workgroup per batch element, two launches for the

@@ -265,7 +265,7 @@ def test_driver_loss_msa_golden(pkg, tables500, lam):
 
 
 @pytest.mark.parametrize("B,L,n_tok,msa", [(1030, 270, 24, 0), (400, 263, 22, 0), (256, 512, 24, 0), (200, 37 * 2, 24, 2),
-                                           (9, 300, 23, 0)])
+                                           (9, 300, 23, 0), (210, 41 * 3, 22, 3)])
 def test_driver_loss_against_oracle(pkg, tables500, B, L, n_tok, msa):
     """d3pm_lvb_hybrid_loss at the launch shapes of the training kernel (one workgroup per element, 256-thread
     workgroups walking several passes, chunks summed by a second launch, the MSA variant) and on the float64 kernel
