@@ -1344,6 +1344,245 @@ __global__ __launch_bounds__(1024) void k_hybrid_loss_pair32(
   D3PM_TL_FLUSH;
 }
 
+// ------------------------------------------------------------------ fused hybrid loss, K = 64 / 128 / 256
+// The arithmetic of k_hybrid_loss_pair32 with a token on G = K / 16 lanes, 16 classes a lane in four interleaved
+// 16-byte pieces (piece h of lane g = classes 4 (g + G h) .. + 3: every access instruction of a lane group covers
+// 16 G contiguous bytes of the row, no staging through LDS on the way in).  64 / G tokens per wave; the sums of a
+// token cross its lanes inside a DPP row (log2 G steps).  Per-class constants come from a workgroup-wide LDS table by
+// piece (one 16-byte broadcast read per piece).  The logits of the two special classes are read from, and their
+// gradient values patched into, a wave-private LDS image of the wave's rows in natural class order.
+// NW waves per workgroup: 4 (256 threads; a batch element split over chunks, the partial sums added by
+// k_loss_finalize) or 16 (one workgroup per batch element, which writes its losses itself).
+template <int G, bool GRAD, int NW>
+__global__ __launch_bounds__(64 * NW) void k_hybrid_loss_wide(
+    ImgArgs a, const float* __restrict__ logits, int loss_type, float hybrid_coeff, float w_vb0,
+    const float* __restrict__ grad_out, LossOut out, float* __restrict__ dlogits, float w_ce0) {
+  constexpr int K = 16 * G, HC = 16, RB = 4 * K, TPW = 64 / G;
+  static_assert(G == 4 || G == 8 || G == 16, "64, 128 or 256 classes");
+  __shared__ __align__(16) float s_tab[3][K];               // a_diag + eps, a_off + eps by x_t; off + eps of Qbar_{t-1}
+  __shared__ __align__(16) float s_w4[K / 4];               // (off + eps)^4 of a piece whose classes share one weight, else -1
+  __shared__ float s_bdo;
+  __shared__ __align__(8) float red[NW * 4 * 2];
+  __shared__ __align__(16) char wide_rows[NW * TPW * RB];   // [waves][tokens of a wave][K]: 4 KB per wave
+  const float eps = a.tb.eps;
+  const int b = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane % G, slot = lane / G;
+  const unsigned tpp = NW * TPW;                            // tokens per pass of the workgroup
+  const unsigned p1 = (unsigned)min(a.npos, (chunk + 1) * a.chunk_pos);
+  const char* __restrict__ lrow = (const char*)(logits + (size_t)b * a.npos * K);
+  char* __restrict__ drow = GRAD ? (char*)(dlogits + (size_t)b * a.npos * K) : nullptr;
+  const char* __restrict__ x0row = (const char*)a.x0 + (size_t)b * a.npos * a.x0_bytes;
+  const char* __restrict__ xtrow = (const char*)a.xt + (size_t)b * a.npos * a.xt_bytes;
+  const unsigned x0sh = a.x0_bytes == 8 ? 3 : 2, xtsh = a.xt_bytes == 8 ? 3 : 2;
+  char* const tokrow = wide_rows + (size_t)(wave * TPW + slot) * RB;        // class c of this lane's token: + 4 c
+  char* const mine = tokrow + 16 * g;                                       // this lane's piece h: + 16 G h
+
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out.rng_counter) *out.rng_counter += out.rng_step;
+
+  const int t = load_index(a.t, b, a.t_bytes, a.tb.T);
+  const bool need_post = (t > 0) && loss_type != D3PM_LOSS_CE;
+  float vd = 0, vo = 0, v_ad = 0, v_ao = 0;
+  if (need_post && threadIdx.x < K) {      // (K <= 256 <= blockDim.x)
+    vd = dg(a.tb.qbar_digest, t - 1, 0, K)[threadIdx.x];
+    vo = dg(a.tb.qbar_digest, t - 1, 1, K)[threadIdx.x];
+    v_ad = dg(a.tb.qone_digest, t, 0, K)[threadIdx.x];
+    v_ao = dg(a.tb.qone_digest, t, 1, K)[threadIdx.x];
+  }
+  // rows and tokens one pass ahead; positions past the end re-read the last one (never stored)
+  v4f_nt zn[4];
+  int x0n = 0, xtn = 0;
+  auto issue = [&](unsigned pos) {
+    const unsigned at = min(pos, p1 - 1);
+    x0n = *reinterpret_cast<const int*>(x0row + ((size_t)at << x0sh));
+    xtn = *reinterpret_cast<const int*>(xtrow + ((size_t)at << xtsh));
+    const char* src = lrow + (size_t)at * RB + 16 * g;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) zn[h] = *reinterpret_cast<const v4f_nt*>(src + 16 * G * h);
+  };
+  unsigned pos = (unsigned)(chunk * a.chunk_pos) + wave * TPW + slot;
+  const unsigned wave_first = (unsigned)(chunk * a.chunk_pos) + wave * TPW;   // (scalar) first token of this wave's pass
+  if (wave_first < p1) issue(pos);
+  unsigned slow_mask = 0;       // bit h: piece h of some lane holds classes of different weights (scalar)
+  float bdo = 0, sum_boe = 0;
+  if (need_post) {
+    if (threadIdx.x < K) {
+      const float bo = vo + eps, bo2 = bo * bo;
+      const float qe = ((bo == partner<1>(bo)) && (bo == partner<2>(bo))) ? 1.0f : 0.0f;
+      const bool same4 = qe != 0.0f && partner<1>(qe) != 0.0f;               // all four classes of the piece
+      s_tab[0][threadIdx.x] = v_ad + eps;
+      s_tab[1][threadIdx.x] = v_ao + eps;
+      s_tab[2][threadIdx.x] = bo;
+      s_w4[threadIdx.x >> 2] = same4 ? bo2 * bo2 : -1.0f;                    // (four threads, one slot, one value)
+      if (threadIdx.x == 0) s_bdo = vd - vo;
+    }
+    __syncthreads();
+    bdo = s_bdo;
+    sum_boe = (1.0f - bdo) + (float)K * eps;                // rows of Qbar_{t-1} sum to one
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      slow_mask |= (__builtin_amdgcn_ballot_w64(s_w4[g + G * h] < 0.0f) != 0 ? 1u : 0u) << h;
+    slow_mask = __builtin_amdgcn_readfirstlane(slow_mask);
+  }
+  float w_vb = w_vb0, w_ce = w_ce0;
+  if (GRAD && grad_out) {
+    const float go = grad_out[b];
+    w_vb *= go;
+    w_ce *= go;
+  }
+  float acc_vb = 0, acc_ce = 0;
+  for (unsigned first = wave_first; first < p1; first += tpp, pos += tpp) {
+    const bool live = pos < p1;
+    f2v e[HC / 2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      e[2 * h] = f2v{zn[h].x, zn[h].y};
+      e[2 * h + 1] = f2v{zn[h].z, zn[h].w};
+      *reinterpret_cast<v4f_nt*>(mine + 16 * G * h) = zn[h];      // the row in natural order, for the two special logits
+    }
+    int x0 = clamp_index(x0n, K), xt = clamp_index(xtn, K);
+    if (first + tpp < p1) issue(pos + tpp);
+    wave_lds_fence();
+    const float z_x0 = *reinterpret_cast<const float*>(tokrow + 4 * x0);
+    const float z_xt = *reinterpret_cast<const float*>(tokrow + 4 * xt);
+    // ---- softmax statistics
+    float m = fmaxf(e[0].x, e[0].y);
+#pragma unroll
+    for (int j = 1; j < HC / 2; ++j) m = fmaxf(fmaxf(m, e[j].x), e[j].y);
+    m = group_max<G>(m);
+    const float mneg = -m * LOG2E;
+    const f2v mneg2 = {mneg, mneg}, l2e2 = {LOG2E, LOG2E};
+    f2v s2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < HC / 2; ++j) {
+      const f2v a2 = e[j] * l2e2 + mneg2;
+      e[j] = f2v{fast_exp2(a2.x), fast_exp2(a2.y)};
+      s2 += e[j];
+    }
+    const float s_ = group_sum<G>(s2.x + s2.y);
+    const float inv = fast_rcp(s_), l2s = fast_log2(s_);
+    const bool count = live && g == 0;                      // the token's sums are counted once
+    const float ce_bits = fmaf(m - z_x0, LOG2E, l2s);       // -log2 softmax(z)[x0]
+    acc_ce += count ? ce_bits : 0.0f;
+    float g_x0 = 0, g_xt = 0;
+    const float e_x0 = fast_exp2(fmaf(z_x0, LOG2E, mneg)), e_xt = fast_exp2(fmaf(z_xt, LOG2E, mneg));
+    if (!need_post) {
+      acc_vb += count ? ce_bits : 0.0f;
+      if constexpr (GRAD) {
+        const float w = (t == 0 ? w_vb : 0.0f) + w_ce, wi = w * inv;
+        const f2v wi2 = {wi, wi};
+#pragma unroll
+        for (int j = 0; j < HC / 2; ++j) e[j] *= wi2;
+        g_x0 = fmaf(e_x0, wi, -w);
+        g_xt = (x0 == xt) ? g_x0 : e_xt * wi;
+      }
+    } else {
+      const float a_d = s_tab[0][xt], a_o = s_tab[1][xt], da = a_d - a_o;
+      const float boe_x0 = s_tab[2][x0], boe_xt = s_tab[2][xt];
+      const float same = (x0 == xt) ? 1.0f : 0.0f;
+      const float bdoi = bdo * inv;
+      const float pi_x0 = e_x0 * inv, pi_xt = e_xt * inv;
+      const float f2_x0 = fmaf(bdo, pi_x0, boe_x0), f2_xt = fmaf(bdo, pi_xt, boe_xt);
+      const float rf_x0 = fast_rcp(f2_x0), rf_xt = fast_rcp(f2_xt);
+      const float b_x0 = boe_x0 + bdo, b_xt = fmaf(same, bdo, boe_xt);
+      const float a_x0 = fmaf(same, da, a_o);
+      const float Zt = fmaf(a_o, sum_boe + bdo, da * b_xt);
+      const float Zm = fmaf(a_o, sum_boe + bdo, da * f2_xt);
+      const float izt = fast_rcp(Zt), izm = fast_rcp(Zm);
+      const float zr = Zm * izt;
+      f2v pr[HC / 2], E2 = {0.0f, 0.0f};
+      float S1 = 0;
+      const f2v bdoi2 = {bdoi, bdoi};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // (the quad of k_hybrid_loss_pair32: four reciprocals from one, every step a packed operation)
+        const v4f_nt w = *reinterpret_cast<const v4f_nt*>(&s_tab[2][4 * (g + G * q)]);
+        const f2v w01 = {w.x, w.y}, w23 = {w.z, w.w};
+        const f2v f01 = e[2 * q] * bdoi2 + w01, f23 = e[2 * q + 1] * bdoi2 + w23;
+        const f2v pp = f01 * f23;
+        const float r = fast_rcp(pp.x * pp.y);
+        const f2v rp = f2v{r, r} * f2v{pp.y, pp.x};
+        pr[2 * q] = w01 * (rp * f23);
+        pr[2 * q + 1] = w23 * (rp * f01);
+        if constexpr (GRAD) {
+          E2 += e[2 * q] * pr[2 * q];
+          E2 += e[2 * q + 1] * pr[2 * q + 1];
+        }
+        if (!((slow_mask >> q) & 1)) {        // (scalar) every lane's piece q has one weight: one logarithm for four classes
+          S1 = fmaf(w.x, fast_log2(s_w4[g + G * q] * r), S1);
+        } else {
+          S1 = fmaf(w.x, fast_log2(pr[2 * q].x), S1);
+          S1 = fmaf(w.y, fast_log2(pr[2 * q].y), S1);
+          S1 = fmaf(w.z, fast_log2(pr[2 * q + 1].x), S1);
+          S1 = fmaf(w.w, fast_log2(pr[2 * q + 1].y), S1);
+        }
+      }
+      S1 = group_sum<G>(S1);
+      float E = 0;
+      if constexpr (GRAD) E = group_sum<G>(E2.x + E2.y);
+      S1 = fmaf(sum_boe, fast_log2(zr), S1);
+      float kls = a_o * S1;
+      kls = fmaf(-a_o * boe_x0, fast_log2(boe_x0 * rf_x0 * zr), kls);
+      kls = fmaf(a_x0 * b_x0, fast_log2(b_x0 * rf_x0 * zr), kls);
+      kls = fmaf((1.0f - same) * da * boe_xt, fast_log2(boe_xt * rf_xt * zr), kls);
+      acc_vb += count ? kls * izt : 0.0f;
+      if constexpr (GRAD) {
+        const float A1 = w_vb * a_o * izm, A2 = w_vb * a_o * izt;
+        const float d_x0 = -A2 * bdo * rf_x0;
+        const float d_xt = w_vb * da * (izm - b_xt * rf_xt * izt);
+        const float p0 = pi_x0 * d_x0 * bdo, pt = pi_xt * d_xt * bdo;
+        const float D = bdo * (A1 - A2 * inv * E);
+        const float Cc = w_ce - (D + p0 + pt);
+        const float nA2i = -A2 * bdoi, Ci = inv * fmaf(bdo, A1, Cc);
+        const f2v nA2i2 = {nA2i, nA2i}, Ci2 = {Ci, Ci};
+#pragma unroll
+        for (int j = 0; j < HC / 2; ++j) e[j] *= nA2i2 * pr[j] + Ci2;
+        g_x0 = fmaf(e_x0, fmaf(nA2i, boe_x0 * rf_x0, Ci), p0 - w_ce);
+        g_xt = fmaf(e_xt, fmaf(nA2i, boe_xt * rf_xt, Ci), pt);
+        if (x0 == xt) g_x0 = g_xt = g_x0 + pt;
+      }
+    }
+    if constexpr (GRAD) {
+      // the gradient row through the image; the two special classes are patched in after every lane's generic values
+      // (a wave's LDS operations execute in order)
+      wave_lds_fence();
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        *reinterpret_cast<v4f_nt*>(mine + 16 * G * h) = v4f_nt{e[2 * h].x, e[2 * h].y, e[2 * h + 1].x, e[2 * h + 1].y};
+      if (g == 0) {
+        *reinterpret_cast<float*>(tokrow + 4 * x0) = g_x0;
+        *reinterpret_cast<float*>(tokrow + 4 * xt) = g_xt;
+      }
+      wave_lds_fence();
+      if (live) {
+        char* dst = drow + (size_t)pos * RB + 16 * g;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          __builtin_nontemporal_store(*reinterpret_cast<const v4f_nt*>(mine + 16 * G * h),
+                                      reinterpret_cast<v4f_nt*>(dst + 16 * G * h));
+      }
+      wave_lds_fence();                       // the image is written again at the top of the next pass
+    }
+  }
+  acc_vb = group_sum<16>(acc_vb);
+  acc_ce = group_sum<16>(acc_ce);
+  if ((lane & 15) == 0) *reinterpret_cast<f2v*>(&red[(wave * 4 + (lane >> 4)) * 2]) = f2v{acc_vb, acc_ce};
+  __syncthreads();
+  if (wave == 0) {
+    f2v v = {0.0f, 0.0f};
+    if (lane < NW * 4) v = *reinterpret_cast<const f2v*>(&red[lane * 2]);
+    const float svb = wave_sum(v.x), sce = wave_sum(v.y);
+    if (lane == 0) {
+      if (a.chunks == 1) {
+        write_losses(out, b, svb, sce, a.npos, loss_type, hybrid_coeff);
+      } else {
+        out.part[((size_t)b * a.chunks + chunk) * 2 + 0] = svb;
+        out.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
+      }
+    }
+  }
+}
+
 // Sums of the per-workgroup partials in chunk order; `unit` converts them to
 // bits (1 for partials already in bits, 1/ln2 for partials in nats).
 __global__ void k_loss_finalize(LossOut out, int B, int chunks, long npos, int loss_type, float hybrid_coeff,
@@ -2025,6 +2264,49 @@ static int structured_hybrid_loss(const d3pm_tables_f32* tb, const float* logits
       default: rc = by_grad(std::integral_constant<int, 32>{}); break;
     }
     if (rc) return rc;
+    if (a.chunks > 1) {
+      hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, o, B, a.chunks, npos, loss_type,
+                         hybrid_coeff, 1.0f);
+      D3PM_LAUNCH_CHECK("k_loss_finalize");
+    }
+    return D3PM_OK;
+  }
+  if (vec && (K == 64 || K == 128 || K == 256) && npos * (long)K * 4 < (1L << 31)) {
+    // 16 classes a lane, K / 16 lanes a token: 256-thread workgroups over chunks of the batch elements, about 1024
+    // of them (four resident per CU), and k_loss_finalize for the chunks' sums.  A caller with a batch that fills the
+    // chip and no workspace gets one workgroup of 16 waves per batch element, which writes its losses itself
+    // (B = 256, L = 512: 44.7 against 45.5 us at K = 256, 24.9 / 25.0 at K = 128, 17.6 / 14.4 at K = 64).
+    const int G = K / 16;
+    ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, 1);
+    const TokenGrid tg = token_grid(B, npos, 256 / G, 1024);
+    const bool one_wg = B >= 192 && tg.chunks > 1 &&
+                        (!partials || partial_bytes < (size_t)B * tg.chunks * 2 * sizeof(float));
+    if (!one_wg) {
+      a.chunks = tg.chunks;
+      a.chunk_pos = tg.chunk_pos;
+    }
+    if (a.chunks > 1) {
+      const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+      D3PM_CHECK_WORKSPACE(partials, partial_bytes, need);
+      o.part = partials;
+    }
+    const float cnorm = (float)((double)grad_scale / ((double)npos * 0.6931471805599453));
+    const float w_vb0 = loss_type == D3PM_LOSS_CE ? 0.0f : cnorm;
+    const float w_ce0 = loss_type == D3PM_LOSS_KL ? 0.0f : (loss_type == D3PM_LOSS_CE ? cnorm : hybrid_coeff * cnorm);
+    auto go = [&](auto gc, auto grad, auto nw) {
+      constexpr int NW = decltype(nw)::value;
+      hipLaunchKernelGGL((k_hybrid_loss_wide<decltype(gc)::value, decltype(grad)::value, NW>), dim3(B * a.chunks),
+                         dim3(64 * NW), 0, s, a, logits, loss_type, hybrid_coeff, w_vb0, grad_out, o, dlogits, w_ce0);
+    };
+    auto by_nw = [&](auto gc, auto grad) {
+      if (one_wg) go(gc, grad, std::integral_constant<int, 16>{});
+      else go(gc, grad, std::integral_constant<int, 4>{});
+    };
+    auto by_grad = [&](auto gc) { if (dlogits) by_nw(gc, std::true_type{}); else by_nw(gc, std::false_type{}); };
+    if (K == 64) by_grad(std::integral_constant<int, 4>{});
+    else if (K == 128) by_grad(std::integral_constant<int, 8>{});
+    else by_grad(std::integral_constant<int, 16>{});
+    D3PM_LAUNCH_CHECK("k_hybrid_loss_wide");
     if (a.chunks > 1) {
       hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, o, B, a.chunks, npos, loss_type,
                          hybrid_coeff, 1.0f);

@@ -315,6 +315,53 @@ def test_token_per_lane_loss_against_oracle(pkg, K, B, npos):
         close(loss_f, loss_ref.detach().numpy(), atol=1e-6, what=f"forward-only loss {kind} K={K}")
 
 
+@pytest.mark.parametrize("K", [64, 128, 256])
+@pytest.mark.parametrize("B,npos", [(3, 70), (200, 130), (2, 1100), (256, 96), (1, 1)])
+def test_wide_structured_loss_against_oracle(pkg, K, B, npos):
+    """The fused loss on column-structured tables with 64, 128 and 256 classes (k_hybrid_loss_wide: 16 classes a lane,
+    K / 16 lanes a token): ragged last passes, chunked batches summed by a second launch, one workgroup per element
+    for a caller without a workspace, t = 0 rows, weighted upstream gradient, forward only -- against the CPU
+    oracle, uniform and absorbing tables (the absorbing column sits inside one 16-byte piece: the per-class
+    logarithms of that piece)."""
+    from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
+    from d3pm_amd.tables import ImageTables
+    T, lam = 12, 0.01
+    betas = pkg.generate_betas(0.02, 0.5, T, "linear")
+    for kind in ("uniform", "absorbing"):
+        p = _oracle_process(betas, kind, K, lam)
+        tb = ImageTables(p.q_mats.to(DEV), p.qT_onestep.to(DEV), transposed_onestep=True)
+        assert tb.structured
+        gen = torch.Generator().manual_seed(K * 1000 + B + npos)
+        x0 = torch.randint(0, K, (B, npos, 1, 1), generator=gen)
+        t = torch.randint(0, T, (B,), generator=gen, dtype=torch.int32)
+        t[0] = 0
+        noise = torch.rand(B, npos, 1, 1, K, generator=gen)
+        logits = (2.0 * torch.randn(B, npos, 1, 1, K, generator=gen)).requires_grad_(True)
+        w = torch.rand(B, generator=gen) + 0.5
+        xt = im.forward_sample(p, x0, t, noise)
+        loss_ref = im.losses_given_xt(p, logits, x0, xt, t)
+        (loss_ref * w).sum().backward()
+        ref = logits.grad.numpy()
+        lg, x0d, xtd, td, wd = (a.detach().to(DEV).contiguous() for a in (logits, x0, xt, t, w))
+        wsb = lib.d3pm_hybrid_loss_workspace(B, npos, K)
+        ws = torch.empty(max(wsb // 4, 1), device=DEV)
+        for workspace in ((ptr(ws), wsb), (None, 0)) if B >= 192 else ((ptr(ws), wsb),):
+            vb, ce, loss = (torch.empty(B, device=DEV) for _ in range(3))
+            dl = torch.full_like(lg, float("nan"))
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0d), 8, ptr(xtd), 8, ptr(td), 4, B, npos,
+                                       LOSS["hybrid"], lam, 1.0, ptr(wd), ptr(vb), ptr(ce), ptr(loss), ptr(dl), None, None,
+                                       0, workspace[0], workspace[1], stream_ptr()))
+            torch.cuda.synchronize()
+            close(loss, loss_ref.detach().numpy(), atol=1e-6, what=f"loss {kind} K={K}")
+            close(vb + lam * ce, loss_ref.detach().numpy(), atol=1e-6, what=f"vb + lam ce {kind} K={K}")
+            close(dl, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {kind} K={K}")
+        loss_f = torch.empty(B, device=DEV)
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg), K, ptr(x0d), 8, ptr(xtd), 8, ptr(td), 4, B, npos, LOSS["hybrid"],
+                                   lam, 1.0, None, None, None, ptr(loss_f), None, None, None, 0, ptr(ws), wsb,
+                                   stream_ptr()))
+        close(loss_f, loss_ref.detach().numpy(), atol=1e-6, what=f"forward-only loss {kind} K={K}")
+
+
 @pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
 def test_k256_matrix_core_tiles_against_oracle(pkg, B, L):
     """K = 256 runs its contractions on the matrix cores in tiles of 64 tokens:
