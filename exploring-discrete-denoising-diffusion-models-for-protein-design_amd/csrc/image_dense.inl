@@ -278,6 +278,122 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
       }
 }
 
+// The same contraction with float32 emulated on the bf16 matrix cores, which on this part run at sixteen times the
+// float32 matrix rate.  Every float32 operand is the exact sum of three bf16 values (x = hi + mid + lo, each the
+// round-to-nearest bf16 of what the ones before it left: 3 x 8 significant bits), so a product is the sum of nine
+// bf16 x bf16 products, each of them exact in the float32 accumulator; the six of magnitude 2^-16 |x y| and above
+// are issued (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi), the three left out are below 2^-23 |x y| together --
+// the size of the float32 rounding the plain contraction makes on every accumulation step.  v_mfma_f32_32x32x16_bf16
+// takes 32 cycles: six per 16 reduction steps against eight 64-cycle v_mfma_f32_32x32x2_f32, 192 cycles against 512.
+// The table arrives pre-split (d3pm_table_split_bf16x3: [3][K / 8][K][8] bf16 per timestep, i.e. a lane's operand of
+// eight consecutive reduction indices for one output column is one 16-byte piece and a wave's load 2 x 512
+// contiguous bytes); the LDS rows stay float32 and every wave splits the row pieces it reads (about 4.5 vector
+// operations per element, issued under the matrix instructions).  Waves, output tiles and the C layout are those of
+// tile_contract_mfma256; the reduction index of lane half h in step c is k = 128 h + 8 c + j.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {        // v_cvt_pk_bf16_f32: a in the low half
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// eight consecutive floats -> their hi / mid / lo bf16 operands
+__device__ __forceinline__ void split_bf16x3(const float4& p, const float4& q, u32x4& hi, u32x4& mid, u32x4& lo) {
+  const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const unsigned h = bf16_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);   // exact
+    const unsigned m = bf16_pair(ra, rb);
+    const float la = ra - __builtin_bit_cast(float, m << 16), lb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    hi[i] = h; mid[i] = m; lo[i] = bf16_pair(la, lb);
+  }
+}
+
+template <int TM>
+__device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict__ Ms, const float* in, float* out) {
+  constexpr int K = 256, LDK = K + 4, RT = TM / 32, NC = K / 16;
+  constexpr int PLANE = K * K * 2, KB = K * 16;         // bytes of one split plane, of one block of 8 reduction indices
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+  const __amdgpu_buffer_rsrc_t Mrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ms), 0, 3 * PLANE, 0x00020000);
+  const int boff = (16 * h) * KB + (64 * wave + r) * 16;
+  const float* arow = in + (size_t)r * LDK + 128 * h;
+  auto load_b = [&](u32x4 (&b)[3][2], int c) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        b[s][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(Mrs, boff + ct * 512, s * PLANE + c * KB, 0));
+  };
+  auto load_a = [&](float4 (&av)[RT][2], int c) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + 8 * c + 4 * f);
+  };
+  auto mm = [&](f32x16& d, const u32x4& x, const u32x4& y) {
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), d, 0, 0, 0);
+  };
+  auto compute = [&](const float4 (&av)[RT][2], const u32x4 (&b)[3][2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      u32x4 ah, am, al;
+      split_bf16x3(av[rt][0], av[rt][1], ah, am, al);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {      // small terms first
+        mm(acc[rt][ct], al, b[0][ct]);
+        mm(acc[rt][ct], am, b[1][ct]);
+        mm(acc[rt][ct], ah, b[2][ct]);
+        mm(acc[rt][ct], am, b[0][ct]);
+        mm(acc[rt][ct], ah, b[1][ct]);
+        mm(acc[rt][ct], ah, b[0][ct]);
+      }
+    }
+  };
+  // The table pieces come from L2: a ring of NB buffers keeps NB - 1 steps' worth of them in flight ((NB - 1) x 24
+  // matrix instructions x 32 cycles of cover); the LDS row pieces are read one step ahead.
+  constexpr int NB = 2;      // measured: a ring of four spills (210 registers) and is 18 % slower
+  static_assert(NC % NB == 0, "the ring is unrolled over whole trips");
+  u32x4 b[NB][3][2];
+  float4 av[2][RT][2];
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i) load_b(b[i], i);
+  load_a(av[0], 0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < NC; c0 += NB) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c = c0 + i;
+      load_b(b[(i + NB - 1) % NB], c + NB - 1 < NC ? c + NB - 1 : NC - 1);     // unconditional (repeats at the end)
+      load_a(av[(i + 1) & 1], c + 1 < NC ? c + 1 : NC - 1);
+      compute(av[i & 1], b[i]);
+    }
+  }
+  __syncthreads();     // every wave has read its A operands: `out` may alias `in`
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        out[(size_t)row * LDK + 64 * wave + 32 * ct + r] = acc[rt][ct][e];
+      }
+}
+
 enum { DENSE_POST = 0, DENSE_LOSS = 1, DENSE_SAMPLE = 2 };
 
 #ifndef D3PM_VALU_PRIO
@@ -296,8 +412,9 @@ struct DenseExtra {
   const float* noise; uint64_t seed, offset; const uint64_t* offset_dev; int64_t* sample;
 };
 
-template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
+template <class L, int MODE, bool GRAD, int NOISE, bool MFMA, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, DenseExtra e) {
+  static_assert(MFMA || !SPLIT, "the bf16 split contraction is a matrix-core path");
   using C = DenseCfg<L, MFMA>;
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
@@ -328,6 +445,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   const bool need_post = (t > 0) && !(MODE == DENSE_LOSS && e.loss_type == D3PM_LOSS_CE);
   const float* Qm = need_post ? a.tb.qbar + (size_t)(t - 1) * K * K : nullptr;
   const float* QmT = (need_post && GRAD) ? a.tb.qbarT + (size_t)(t - 1) * K * K : nullptr;
+  const uint16_t* QmS = (SPLIT && need_post) ? a.tb.qbar_bf16x3 + (size_t)(t - 1) * 3 * K * K : nullptr;
+  const uint16_t* QmTS = (SPLIT && need_post && GRAD) ? a.tb.qbarT_bf16x3 + (size_t)(t - 1) * 3 * K * K : nullptr;
 
   float w_vb = 0, w_ce = 0;
   if constexpr (MODE == DENSE_LOSS) {
@@ -465,7 +584,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         // the co-resident workgroup's per-token phase issues ahead of this stream of long matrix instructions,
         // which loses next to nothing by it
         __builtin_amdgcn_s_setprio(0);
-        tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
+        if constexpr (SPLIT) tile_contract_bf16x3<C::TM>(QmS, s_pi, s_f2);
+        else tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
         __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
       } else tile_contract<L>(Qm, K, s_pi, s_f2);
     }
@@ -596,7 +716,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       if (need_post) {
         if constexpr (MFMA) {
           __builtin_amdgcn_s_setprio(0);
-          tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
+          if constexpr (SPLIT) tile_contract_bf16x3<C::TM>(QmTS, s_f2, s_gp);
+          else tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
           __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
         } else tile_contract<L>(QmT, K, s_f2, s_gp);
       }
@@ -682,19 +803,24 @@ static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0
 // the caller's with the VALU contraction.
 using MfmaLayout = Layout<16, 16, true, true>;
 
+// third argument of f: 0 = VALU contraction, 1 = float32 matrix instructions, 2 = float32 emulated with three bf16
+// pieces per operand (taken when the caller built both split tables)
 template <class L, class F>
 static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
   if constexpr (L::VEC) {
-    if (tb->K == 256) return f(MfmaLayout{}, std::true_type{});
+    if (tb->K == 256) {
+      if (tb->qbar_bf16x3 && tb->qbarT_bf16x3) return f(MfmaLayout{}, std::integral_constant<int, 2>{});
+      return f(MfmaLayout{}, std::integral_constant<int, 1>{});
+    }
   }
-  return f(L{}, std::false_type{});
+  return f(L{}, std::integral_constant<int, 0>{});
 }
 
-template <class L, int MODE, bool GRAD, int NOISE, bool MFMA>
+template <class L, int MODE, bool GRAD, int NOISE, bool MFMA, bool SPLIT = false>
 static int launch_tile(const d3pm_tables_f32* tb, const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   using C = DenseCfg<L, MFMA>;
   const size_t sh = (size_t)C::TM * (tb->K + C::PAD) * sizeof(float) * (MFMA ? 1 : (GRAD ? 3 : 2));
-  auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA>;
+  auto kern = k_dense_tile<L, MODE, GRAD, NOISE, MFMA, SPLIT>;
   if (sh > 48 * 1024) {
     hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -764,11 +890,11 @@ static int dense_posterior_logits(const d3pm_tables_f32* tb, const void* x_start
     }
     return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
       using L = decltype(lay2);
-      constexpr bool MF = decltype(mf)::value;
+      constexpr bool MF = decltype(mf)::value != 0, SP = decltype(mf)::value == 2;
       ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
       DenseExtra e{};
       e.logits = (const float*)x_start; e.ld = ld; e.out = out;
-      return launch_tile<L, DENSE_POST, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
+      return launch_tile<L, DENSE_POST, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
     });
   });
 }
@@ -784,7 +910,7 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
     using L = decltype(lay);
     return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
       using L = decltype(lay2);
-      constexpr bool MF = decltype(mf)::value;
+      constexpr bool MF = decltype(mf)::value != 0, SP = decltype(mf)::value == 2;
       ImgArgs a = make_dense_args<L, MF>(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos);
       const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
       D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
@@ -792,8 +918,8 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
       e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
       e.rng_counter = o.rng_counter; e.rng_step = o.rng_step;
-      const int rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s)
-                             : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
+      const int rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s)
+                             : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
       if (rc) return rc;
       LossOut oo = o;
       oo.part = e.part;
@@ -815,14 +941,14 @@ static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long l
     using L = decltype(lay);
     return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
       using L = decltype(lay2);
-      constexpr bool MF = decltype(mf)::value;
+      constexpr bool MF = decltype(mf)::value != 0, SP = decltype(mf)::value == 2;
       ImgArgs a = make_dense_args<L, MF>(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos);
       DenseExtra e{};
       e.logits = logits; e.ld = ld; e.noise = noise; e.seed = seed; e.offset = offset; e.offset_dev = offset_dev;
       e.sample = sample; e.probs = probs;
-      if (noise_kind == D3PM_NOISE_UNIFORM) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_UNIFORM, MF>(tb, a, e, B, s);
-      if (noise_kind == D3PM_NOISE_GUMBEL) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_GUMBEL, MF>(tb, a, e, B, s);
-      return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_PHILOX, MF>(tb, a, e, B, s);
+      if (noise_kind == D3PM_NOISE_UNIFORM) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_UNIFORM, MF, SP>(tb, a, e, B, s);
+      if (noise_kind == D3PM_NOISE_GUMBEL) return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
+      return launch_tile<L, DENSE_SAMPLE, false, D3PM_NOISE_PHILOX, MF, SP>(tb, a, e, B, s);
     });
   });
 }

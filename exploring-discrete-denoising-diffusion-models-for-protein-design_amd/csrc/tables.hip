@@ -237,6 +237,32 @@ __global__ void k_cast_f32(const double* __restrict__ table, long st, long sr, l
   }
 }
 
+// float32 [T][K][K] -> bf16 [T][3][K/8][K][8]: x = hi + mid + lo exactly, each piece the round-to-nearest bf16 of what
+// the ones before it left (the two subtractions are exact in float32).  One thread per (block of eight rows, column):
+// eight strided reads, three 16-byte writes.
+__global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ table, int K, uint16_t* __restrict__ out) {
+  const int t = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;       // kb * K + col
+  if (e >= (K / 8) * K) return;
+  const int kb = e / K, col = e - kb * K;
+  const float* m = table + (size_t)t * K * K + (size_t)kb * 8 * K + col;
+  uint16_t h[8], md[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = m[(size_t)j * K];
+    const __bf16 xh = (__bf16)x;
+    const float r1 = x - (float)xh;
+    const __bf16 xm = (__bf16)r1;
+    const float r2 = r1 - (float)xm;
+    const __bf16 xl = (__bf16)r2;
+    h[j] = __builtin_bit_cast(uint16_t, xh); md[j] = __builtin_bit_cast(uint16_t, xm); lo[j] = __builtin_bit_cast(uint16_t, xl);
+  }
+  const size_t plane = (size_t)(K / 8) * K * 8;
+  uint16_t* o = out + (size_t)t * 3 * plane + (size_t)e * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { o[j] = h[j]; o[plane + j] = md[j]; o[2 * plane + j] = lo[j]; }
+}
+
 // 64-bit content fingerprint of a strided [T,K,K] float64 table: the sum, modulo 2^64, of every element's bit
 // pattern times an odd multiplier derived from its index (splitmix64 of the index).  Integer addition is
 // associative, so the order in which workgroups add their partial sums does not matter.
@@ -276,7 +302,7 @@ static int launch_chain(int K, int T, const double* mats, long st, long sr, long
 using namespace d3pm;
 
 extern "C" const char* d3pm_last_error(void) { return g_err; }
-extern "C" int d3pm_abi_version(void) { return 9; }
+extern "C" int d3pm_abi_version(void) { return 10; }
 
 extern "C" int d3pm_build_tables_f64(int kind, int K, int T, int bands, const double* betas, double* q_onestep,
                                      double* q_mats, void* stream) {
@@ -345,5 +371,14 @@ extern "C" int d3pm_table_to_f32(const double* table, long st, long sr, long sc,
   const int nb = min(64, (K * K + 255) / 256);
   hipLaunchKernelGGL(k_cast_f32, dim3(nb, T), dim3(256), 0, (hipStream_t)stream, table, st, sr, sc, K, out);
   D3PM_LAUNCH_CHECK("k_cast_f32");
+  return D3PM_OK;
+}
+
+extern "C" int d3pm_table_split_bf16x3(const float* table, int T, int K, uint16_t* out, void* stream) {
+  D3PM_CHECK_ARG(table && out && T >= 1, "null pointer or empty table");
+  D3PM_CHECK_ARG(K >= 8 && K % 8 == 0, "the split layout needs K to be a multiple of 8, got %d", K);
+  const int n = (K / 8) * K;
+  hipLaunchKernelGGL(k_split_bf16x3, dim3((n + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, table, K, out);
+  D3PM_LAUNCH_CHECK("k_split_bf16x3");
   return D3PM_OK;
 }

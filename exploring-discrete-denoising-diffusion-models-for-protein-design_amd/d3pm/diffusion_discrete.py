@@ -243,17 +243,21 @@ class DiscreteDiffusion:
         self._tables: Optional[ImageTables] = None
         self._tables_key = None
         self.force_dense = False
+        # how dense tables with 256 classes contract (ImageTables): 'bf16x3' = float32 emulated on the bf16 matrix
+        # instructions, 'f32' = the float32 matrix instructions; set before the first call that uses the tables
+        self.dense_matmul = "bf16x3"
 
     # ------------------------------------------------------------------ tables
     def tables(self) -> ImageTables:
         """Digest / float32 copies of the current ``q_mats`` and
         ``transpose_q_onestep_mats`` (rebuilt if a caller replaced them)."""
         a, b = self.q_mats, self.transpose_q_onestep_mats
-        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, tuple(b.stride()), self.force_dense)
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, tuple(b.stride()), self.force_dense, self.dense_matmul)
         if self._tables is None or key != self._tables_key:
             with torch.cuda.device(self.device):
                 self._tables = ImageTables(a.to(self.device), b.to(self.device), eps=self.eps,
-                                           transposed_onestep=True, force_dense=self.force_dense)
+                                           transposed_onestep=True, force_dense=self.force_dense,
+                                           dense_matmul=self.dense_matmul)
             self._tables_key = key
         return self._tables
 

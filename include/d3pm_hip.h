@@ -123,6 +123,15 @@ int d3pm_table_fingerprint(const double* table, long st, long sr, long sc, int T
 int d3pm_table_to_f32(const double* table, long st, long sr, long sc, int T, int K,
                       float* out, void* stream);
 
+/* A contiguous float32 [T][K][K] table (row = reduction index, column = output
+ * class of the contraction it serves) as three bf16 planes whose sum is the
+ * float32 value exactly: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid),
+ * round to nearest.  out: bf16 [T][3][K/8][K][8] -- plane, block of eight
+ * consecutive rows, column, row within the block -- 6 T K K bytes; K a multiple
+ * of 8.  Serves the `a.to(float32)` + matmul of _at_onehot,
+ * d3pm/diffusion_discrete.py:242-247, on the bf16 matrix instructions. */
+int d3pm_table_split_bf16x3(const float* table, int T, int K, uint16_t* out, void* stream);
+
 /* Float32 view of the tables a kernel needs.  `structured` selects the digest
  * path (O(K) per token) or the dense path (gathers + K x K contraction). */
 typedef struct d3pm_tables_f32 {
@@ -134,6 +143,12 @@ typedef struct d3pm_tables_f32 {
   const float* qbar;         /* [T][K][K] q_mats, float32 (dense only)    */
   const float* qoneT;        /* [T][K][K] transpose_q_onestep_mats (dense)*/
   const float* qbarT;        /* [T][K][K] q_mats transposed (dense, for the backward contraction) */
+  /* Optional (both or neither; K = 256): qbar / qbarT as d3pm_table_split_bf16x3 writes them.  When present the
+   * K x K contractions of _at_onehot (:242) run as float32 emulated on the bf16 matrix instructions (three bf16
+   * pieces per operand, six products per term: relative error below 2^-22 per product, against the 2^-24 of a
+   * float32 multiply-add); when NULL, on the float32 matrix instructions. */
+  const uint16_t* qbar_bf16x3;
+  const uint16_t* qbarT_bf16x3;
 } d3pm_tables_f32;
 
 /* Float64 view for the protein-style kernels (structured only). */

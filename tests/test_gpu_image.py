@@ -615,7 +615,8 @@ def test_raw_ctypes_binding_as_documented(pkg):
     class TablesF32(C.Structure):
         _fields_ = [("K", C.c_int), ("T", C.c_int), ("structured", C.c_int), ("eps", C.c_float),
                     ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p),
-                    ("qbar", C.c_void_p), ("qoneT", C.c_void_p), ("qbarT", C.c_void_p)]
+                    ("qbar", C.c_void_p), ("qoneT", C.c_void_p), ("qbarT", C.c_void_p),
+                    ("qbar_bf16x3", C.c_void_p), ("qbarT_bf16x3", C.c_void_p)]
 
     K, T, B, npos = 32, 500, 256, 40
     d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
@@ -631,7 +632,7 @@ def test_raw_ctypes_binding_as_documented(pkg):
                                  C.c_void_p(dg.data_ptr()), C.c_void_p(viol.data_ptr() + off), C.c_void_p(s))
         assert rc == 0
     assert viol.tolist() == [0, 0]
-    tb = TablesF32(K, T, 1, 1e-6, dg_bar.data_ptr(), dg_one.data_ptr(), None, None, None)
+    tb = TablesF32(K, T, 1, 1e-6, dg_bar.data_ptr(), dg_one.data_ptr(), None, None, None, None, None)
     gen = torch.Generator().manual_seed(4)
     x0 = torch.randint(0, K, (B, npos, 1, 1), generator=gen).to(DEV)
     t = torch.randint(0, T, (B,), generator=gen, dtype=torch.int32).to(DEV)
