@@ -285,11 +285,9 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
 // are issued (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi), the three left out are below 2^-23 |x y| together --
 // the size of the float32 rounding the plain contraction makes on every accumulation step.  v_mfma_f32_32x32x16_bf16
 // takes 32 cycles: six per 16 reduction steps against eight 64-cycle v_mfma_f32_32x32x2_f32, 192 cycles against 512.
-// The table arrives pre-split (d3pm_table_split_bf16x3: [3][K / 8][K][8] bf16 per timestep, i.e. a lane's operand of
-// eight consecutive reduction indices for one output column is one 16-byte piece and a wave's load 2 x 512
-// contiguous bytes); the LDS rows stay float32 and every wave splits the row pieces it reads (about 4.5 vector
-// operations per element, issued under the matrix instructions).  Waves, output tiles and the C layout are those of
-// tile_contract_mfma256; the reduction index of lane half h in step c is k = 128 h + 8 c + j.
+// The table arrives pre-split (d3pm_table_split_bf16x3: a lane's operand of eight reduction indices for one output
+// class is one 16-byte piece); the LDS rows stay float32 and every wave splits the row pieces it reads (about 4.5
+// vector operations per element).  Waves, output tiles and the C layout are those of tile_contract_mfma256.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -316,7 +314,6 @@ __device__ __forceinline__ void split_bf16x3(const float4& p, const float4& q, u
 template <int TM>
 __device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict__ Ms, const float* in, float* out) {
   constexpr int K = 256, LDK = K + 4, RT = TM / 32, NC = K / 16;
-  constexpr int PLANE = K * K * 2, KB = K * 16;         // bytes of one split plane, of one block of 8 reduction indices
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   f32x16 acc[RT][2];
@@ -326,23 +323,27 @@ __device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict_
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
+  // Operand image (d3pm_table_split_bf16x3): piece p of (reduction block u, class tile mt, lane kg << 4 | mm) at byte
+  // ((u 16 + mt) 3 + p) 1024 + (kg 16 + mm) 16, holding reduction indices 32 u + 16 (s >> 2) + 4 kg + (s & 3).
+  // Step c of lane half h takes (u, kg) = (c >> 1, 2 (c & 1) + h); its output class is 64 wave + 32 ct + r.
   const __amdgpu_buffer_rsrc_t Mrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ms), 0, 3 * PLANE, 0x00020000);
-  const int boff = (16 * h) * KB + (64 * wave + r) * 16;
-  const float* arow = in + (size_t)r * LDK + 128 * h;
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ms), 0, 3 * K * K * 2, 0x00020000);
+  const int boff = (4 * wave + (r >> 4)) * 3072 + h * 256 + (r & 15) * 16;
+  const float* arow = in + (size_t)r * LDK + 4 * h;
   auto load_b = [&](u32x4 (&b)[3][2], int c) {
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
-        b[s][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(Mrs, boff + ct * 512, s * PLANE + c * KB, 0));
+        b[s][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            Mrs, boff + s * 1024, (c >> 1) * 49152 + (c & 1) * 512 + ct * 6144, 0));
   };
   auto load_a = [&](float4 (&av)[RT][2], int c) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int f = 0; f < 2; ++f)
-        av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + 8 * c + 4 * f);
+        av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + 32 * (c >> 1) + 8 * (c & 1) + 16 * f);
   };
   auto mm = [&](f32x16& d, const u32x4& x, const u32x4& y) {
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), d, 0, 0, 0);
@@ -786,6 +787,12 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   }
 }
 
+}  // namespace d3pm
+
+#include "image_dense256.inl"
+
+namespace d3pm {
+
 // ------------------------------------------------------------------ host side
 template <class L, bool MFMA>
 static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0b, const void* xt, int xtb, const void* t,
@@ -918,8 +925,17 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
       e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
       e.rng_counter = o.rng_counter; e.rng_step = o.rng_step;
-      const int rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s)
-                             : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
+      int rc;
+      if constexpr (SP) {
+        // 256 classes with the split tables: the training form (gradient asked for) on the register-tile kernel
+        // (251-261 us against the tile kernel's 272 at B = 128 x 1024 tokens; forward only the tile kernel is
+        // the faster one, 124 against 128-135)
+        rc = dlogits ? launch_loss256(a, e, B, s)
+                     : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
+      } else {
+        rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s)
+                     : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
+      }
       if (rc) return rc;
       LossOut oo = o;
       oo.part = e.part;

@@ -1,0 +1,367 @@
+// The dense K = 256 training loss (vb_terms_bpd + cross_entropy_start + their
+// gradient, d3pm/diffusion_discrete.py:462-582, for Gaussian and banded
+// transition tables) with every per-token quantity held in registers from the
+// logits load to the gradient store.  Included by image_structured.hip after
+// image_dense.inl (same translation unit, namespace d3pm).
+//
+// A wave owns 16 tokens.  Lane l = (kg << 4) | tok holds, for token `tok`, the 64
+// classes 16 mt + 4 kg + r (mt = 0..15, r = 0..3): element (mt, r) of every
+// per-class array.  In that order
+//   * a token's row is read and written as sixteen 16-byte pieces per lane;
+//   * the two K x K contractions run as  out^T = table-image x act^T  on
+//     v_mfma_f32_16x16x32_bf16 with the table as the A operand (rows = output
+//     classes) and the wave's activations as the B operand (columns = tokens):
+//     accumulator tile mt of the result is element (mt, .) of the output array,
+//     and elements (2u, .), (2u+1, .) of an input array are the B operand of
+//     reduction block u -- so softmax -> contraction -> KL terms -> contraction
+//     -> softmax backward never leave the lane's registers;
+//   * sums over a token's classes are 63 additions in registers and two
+//     cross-lane steps (lanes tok, tok + 16, tok + 32, tok + 48).
+// float32 is emulated on the bf16 matrix pipe as in tile_contract_bf16x3 (three
+// pieces per operand, six products); the activations are split once per use by
+// the wave that owns them.  The table (d3pm_table_split_bf16x3's operand image,
+// 384 KB per timestep and orientation) streams from L2 through a three-stage LDS
+// ring of 24 KB stages shared by the workgroup's four waves, one barrier per
+// stage; a stage is 8 output-class tiles x 3 pieces x 1 KB, byte for byte the
+// image in global memory, and a wave's A-operand read is 1 KB of consecutive
+// bytes (no bank conflicts).  72 KB of LDS and at most 256 registers: two
+// workgroups per CU, one's per-token arithmetic under the other's contraction.
+
+namespace d3pm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RT_STAGE = 8 * 3 * 1024;        // bytes of one ring stage
+constexpr int RT_TABLE = 3 * 256 * 256 * 2;   // bytes of one timestep's operand image
+
+__device__ __forceinline__ float quad_lanes_sum(float x) {      // over lanes tok, tok+16, tok+32, tok+48
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+__device__ __forceinline__ float quad_lanes_max(float x) {
+  x = fmaxf(x, __shfl_xor(x, 16));
+  x = fmaxf(x, __shfl_xor(x, 32));
+  return x;
+}
+
+// Table stages go from L2 to the ring by LDS-DMA loads (buffer_load ... lds: no register destination; a wave's
+// instruction moves 64 x 16 consecutive bytes, which is what a stage's image is made of).
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ void ring_dma(const __amdgpu_buffer_rsrc_t& trs, char* ring, int s) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the lane's byte offset is formed here, every time, from the lane index (three vector operations): kept in a
+  // register across the kernel it gets spilled, and a scratch reload in front of each DMA instruction waits for
+  // the one before it (the counter of vector-memory operations completes in order)
+  int off;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(off));
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % 3) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
+                                             s * RT_STAGE + i * 4096 + wave * 1024, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const char* table) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, RT_TABLE, 0x00020000);
+}
+// Requests the first two stages of `table`.  Call once every wave of the workgroup is past its last read of the
+// ring (regtile_contract ends with a barrier), as early as the table is known: the stages arrive under whatever the
+// waves do until the contraction.
+__device__ __forceinline__ void ring_begin(const char* table, char* ring) {
+  const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
+  ring_dma(trs, ring, 0);
+  ring_dma(trs, ring, 1);
+}
+
+// out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all 256 classes of `act` taking
+// part (act in element order).  Every wave of the workgroup calls this together, after ring_begin(table).
+//
+// The contraction is a flat sequence of 128 blocks (reduction block u, class tile mt): three 1 KB piece reads and
+// six matrix instructions each.  Stage s = blocks 8 s .. 8 s + 7 sits in ring buffer s % 3; its DMA is issued at the
+// start of stage s - 2 (its buffer's previous content, stage s - 3, was last read before the barrier that ends that
+// stage), waited for and published by the barrier at the end of stage s - 2, and read from the end of stage s - 1
+// on: the piece reads run two blocks ahead of the matrix instructions and cross the stage boundaries, so neither a
+// barrier nor an LDS latency sits between two stages' matrix instructions.
+__device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring, const f32x4 (&act)[16],
+                                                 f32x4 (&out)[16]) {
+  const int lane = threadIdx.x & 63;
+  const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
+  auto mm = [&](f32x4& d, const u32x4& x, const u32x4& y) {
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), d, 0, 0, 0);
+  };
+  struct Frag { u32x4 hi, mid, lo; };
+  auto read_frag = [&](int j) {       // block j = 8 s + ml
+    const char* st = ring + ((j >> 3) % 3) * RT_STAGE + (j & 7) * 3072 + lane * 16;
+    Frag f;
+    f.hi = *reinterpret_cast<const u32x4*>(st);
+    f.mid = *reinterpret_cast<const u32x4*>(st + 1024);
+    f.lo = *reinterpret_cast<const u32x4*>(st + 2048);
+    return f;
+  };
+  // what the caller computed for `act` is complete here: left free, the compiler sinks the producers of act's
+  // later elements into the loop and keeps their inputs alive, spilled, across it.  An empty asm statement that
+  // takes every element as an in-out operand (no instruction is emitted) pins them, the scheduling fence keeps
+  // the machine scheduler from moving anything across
+#pragma unroll
+  for (int mt = 0; mt < 16; ++mt) asm volatile("" : "+v"(const_cast<f32x4&>(act[mt])));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int mt = 0; mt < 16; ++mt) out[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  __syncthreads();          // stages 0 and 1 have landed (the barrier's fence waits for the DMA) and are visible
+  __builtin_amdgcn_s_setprio(0);     // the co-resident workgroup's per-token arithmetic issues ahead of this stream
+  Frag fr[3];
+  fr[0] = read_frag(0);
+  fr[1] = read_frag(1);
+  // the activations' pieces of reduction block u + 1 are formed in the middle of block u's second stage, pinned
+  // there by scheduling fences (36 vector operations that issue under the matrix instructions around them); left
+  // free, the compiler forms all eight blocks' pieces ahead of the loop and spills them
+  struct Pieces { u32x4 hi, mid, lo; };
+  Pieces pc[2];
+  __builtin_amdgcn_sched_barrier(0);
+  split_bf16x3(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].mid, pc[0].lo);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const Pieces& b = pc[u & 1];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int s = 2 * u + half;
+      if (s + 2 < 16) ring_dma(trs, ring, s + 2);
+#pragma unroll
+      for (int ml = 0; ml < 8; ++ml) {
+        const int j = 8 * s + ml;
+        if (j + 2 < 128) fr[(j + 2) % 3] = read_frag(j + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag& f = fr[j % 3];
+        f32x4& d = out[8 * half + ml];
+        mm(d, f.lo, b.hi);      // small terms first
+        mm(d, f.mid, b.mid);
+        mm(d, f.hi, b.lo);
+        mm(d, f.mid, b.hi);
+        mm(d, f.hi, b.mid);
+        mm(d, f.hi, b.hi);
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 1 && ml == 3 && u + 1 < 8) {
+          Pieces& nx = pc[(u + 1) & 1];
+          split_bf16x3(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.mid, nx.lo);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra e) {
+  extern __shared__ __align__(16) char ring[];
+  __shared__ float red[2 * 4];
+  constexpr int K = 256;
+  const float eps = a.tb.eps;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && e.rng_counter) *e.rng_counter += e.rng_step;
+  // workgroup -> (batch element, chunk) as in k_dense_tile: all chunks of an element on one XCD
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int b = (within / a.chunks) * 8 + xcd, chunk = within % a.chunks;
+  if (b >= e.B) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tok = lane & 15, kg = lane >> 4;
+  const int t = __builtin_amdgcn_readfirstlane(load_index(a.t, b, a.t_bytes, a.tb.T));
+  const bool need_post = (t > 0) && e.loss_type != D3PM_LOSS_CE;
+  const char* tableF = need_post ? reinterpret_cast<const char*>(a.tb.qbar_bf16x3) + (size_t)(t - 1) * RT_TABLE : nullptr;
+  const char* tableB =
+      (need_post && GRAD) ? reinterpret_cast<const char*>(a.tb.qbarT_bf16x3) + (size_t)(t - 1) * RT_TABLE : nullptr;
+  const float gb = e.grad_scale * ((GRAD && e.grad_out) ? e.grad_out[b] : 1.0f);
+  const float cnorm = gb / ((float)a.npos * LN2);
+  const float w_vb = (e.loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
+  const float w_ce = (e.loss_type == D3PM_LOSS_KL) ? 0.0f : (e.loss_type == D3PM_LOSS_CE ? cnorm : e.hybrid_coeff * cnorm);
+  float acc_vb = 0, acc_ce = 0;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+#ifdef D3PM_TIMELINE
+  // debug builds: time spent per phase, summed over this wave's tiles (slot 0: start, 6: end)
+  unsigned long long ph_[TL_POINTS] = {}, last_ = wall_clock64();
+  ph_[0] = last_;
+#define D3PM_PHASE256(i) do { const unsigned long long now_ = wall_clock64(); ph_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define D3PM_PHASE256(i) do {} while (0)
+#endif
+  __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
+  if (need_post) ring_begin(tableF, ring);
+  for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += 64) {
+    const long pos = tile0 + 16 * wave + tok;
+    const bool live = pos < p1;
+    const long n = (long)b * a.npos + (live ? pos : tile0);
+    const int x0 = load_index(a.x0, n, a.x0_bytes, K);
+    const int xt = load_index(a.xt, n, a.xt_bytes, K);
+    // rows of this tile through descriptors based at the tile's first row (rows are K floats: ld == K here)
+    const long row0 = (long)b * a.npos + tile0;
+    const int rows = (int)min((long)64, p1 - tile0);
+    const __amdgpu_buffer_rsrc_t zrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.logits) + row0 * K, 0, rows * K * 4, 0x00020000);
+    const int rowoff = (live ? 16 * wave + tok : 0) * (K * 4) + 16 * kg;
+    auto load_row4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, int mt) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64 * mt, 0, 0));
+    };
+    // ---- softmax of the token's logits, cross-entropy term
+    f32x4 v[16];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) v[mt] = load_row4(zrs, rowoff, mt);
+    const float zx0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, rowoff - 16 * kg + 4 * x0, 0, 0));
+    float m = v[0][0];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, v[mt][r]);
+    m = quad_lanes_max(m);
+    float sum = 0;
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[mt][r] = fast_exp2((v[mt][r] - m) * LOG2E); sum += v[mt][r]; }
+    sum = quad_lanes_sum(sum);
+    const float inv = fast_rcp(sum);
+    const float ce = fmaf(fast_log2(sum), LN2, m) - zx0;
+    const float pscale = live ? inv : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) v[mt] *= pscale;
+    float vb = ce;
+    D3PM_PHASE256(1);
+    if (need_post) {
+      // ---- f2 = pi @ Qbar_{t-1}
+      f32x4 f2[16];
+      regtile_contract(tableF, ring, v, f2);
+      if (GRAD) ring_begin(tableB, ring);
+      else if (tile0 + 64 < p1) ring_begin(tableF, ring);
+      D3PM_PHASE256(2);
+      // ---- KL(q || p) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of Qbar_{t-1} + eps,
+      // f2 += eps), one log per class; d loss / d f2 replaces f2 in its registers
+      const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.tb.qoneT) + (size_t)t * K * K, 0, K * K * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.tb.qbar) + (size_t)(t - 1) * K * K, 0, K * K * 4, 0x00020000);
+      const int aoff = xt * (K * 4) + 16 * kg, boff = x0 * (K * 4) + 16 * kg;
+      f32x4 av[16], bv[16];
+#pragma unroll
+      for (int mt = 0; mt < 16; ++mt) {
+        av[mt] = load_row4(ars, aoff, mt) + eps;
+        bv[mt] = load_row4(brs, boff, mt) + eps;
+      }
+      float zm = 0, zt = 0;
+#pragma unroll
+      for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f2[mt][r] += eps;
+          zm = fmaf(av[mt][r], f2[mt][r], zm);
+          zt = fmaf(av[mt][r], bv[mt][r], zt);
+        }
+      zm = quad_lanes_sum(zm);
+      zt = quad_lanes_sum(zt);
+      const float izm = fast_rcp(zm), izt = fast_rcp(zt), zr = zm * izt;
+      const float wv = live ? w_vb : 0.0f;
+      float kl = 0;
+#pragma unroll
+      for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float br = bv[mt][r] * fast_rcp(f2[mt][r]);
+          kl = fmaf(av[mt][r] * bv[mt][r], fast_log2(br * zr), kl);
+          if constexpr (GRAD) f2[mt][r] = wv * av[mt][r] * fmaf(-br, izt, izm);
+        }
+      vb = quad_lanes_sum(kl) * izt * LN2;
+      D3PM_PHASE256(3);
+      if constexpr (GRAD) {
+        // ---- d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T, then through the softmax (re-formed from the
+        // re-read row with the same max and 1 / sum: bit-identical) plus the cross-entropy term
+        f32x4 gp[16];
+        regtile_contract(tableB, ring, f2, gp);
+        if (tile0 + 64 < p1) ring_begin(tableF, ring);
+        D3PM_PHASE256(4);
+        f32x4 pi[16];
+        float dot = 0;
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+          const f32x4 z = load_row4(zrs, rowoff, mt);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pi[mt][r] = fast_exp2((z[r] - m) * LOG2E) * inv;
+            dot = fmaf(pi[mt][r], gp[mt][r], dot);
+          }
+        }
+        dot = quad_lanes_sum(dot);
+        if (live) {
+          const int d = x0 - 4 * kg;                               // element (d >> 4, d & 3) is class x0, if this lane has it
+          const int mt_hit = (d >= 0 && (d & 12) == 0) ? (d >> 4) : -1;
+          float sel[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sel[r] = ((d & 3) == r) ? w_ce : 0.0f;
+          const __amdgpu_buffer_rsrc_t grs =
+              __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
+#pragma unroll
+          for (int mt = 0; mt < 16; ++mt) {
+            const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
+            f32x4 gz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              gz[r] = fmaf(-hit, sel[r], pi[mt][r] * (gp[mt][r] - dot) + w_ce * pi[mt][r]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gz), grs, rowoff + 64 * mt, 0, 0);
+          }
+        }
+      }
+    } else if constexpr (GRAD) {
+      // t == 0 (the bound term is the cross-entropy) or a cross-entropy-only loss: no contraction
+      if (live) {
+        const float w = (t == 0 ? w_vb : 0.0f) + w_ce;
+        const int d = x0 - 4 * kg;
+        const int mt_hit = (d >= 0 && (d & 12) == 0) ? (d >> 4) : -1;
+        float sel[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sel[r] = ((d & 3) == r) ? w : 0.0f;
+        const __amdgpu_buffer_rsrc_t grs =
+            __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+          const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
+          f32x4 gz;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gz[r] = fmaf(-hit, sel[r], w * v[mt][r]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gz), grs, rowoff + 64 * mt, 0, 0);
+        }
+      }
+    }
+    if (kg == 0 && live) { acc_vb += vb; acc_ce += ce; }
+    D3PM_PHASE256(5);
+  }
+#ifdef D3PM_TIMELINE
+  ph_[6] = wall_clock64();
+  ph_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);              // HW_REG_HW_ID
+  ph_[8] = __builtin_amdgcn_s_getreg((3 << 11) | 20);              // HW_REG_XCC_ID
+  if (blockIdx.x < 256 && lane == 0)
+    for (int i_ = 0; i_ < TL_POINTS; ++i_) g_timeline[blockIdx.x][wave][i_] = ph_[i_];
+#endif
+  acc_vb = wave_sum(acc_vb);
+  acc_ce = wave_sum(acc_ce);
+  if (lane == 0) { red[2 * wave] = acc_vb; red[2 * wave + 1] = acc_ce; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float svb = 0, sce = 0;
+    for (int w = 0; w < 4; ++w) { svb += red[2 * w]; sce += red[2 * w + 1]; }
+    e.part[((size_t)b * a.chunks + chunk) * 2 + 0] = svb;
+    e.part[((size_t)b * a.chunks + chunk) * 2 + 1] = sce;
+  }
+}
+
+static int launch_loss256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
+  auto kern = k_dense_loss256<true>;
+  const int sh = 3 * RT_STAGE;
+  hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+  if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  DenseExtra ee = e;
+  ee.B = B;
+  hipLaunchKernelGGL(kern, dim3(((B + 7) / 8) * 8 * a.chunks), dim3(256), sh, s, a, ee);
+  D3PM_LAUNCH_CHECK("k_dense_loss256");
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

@@ -90,7 +90,7 @@ void need_image_tables(at::TensorList tables, int64_t K, int64_t T, bool structu
       for (int i = 5; i < 7; ++i) {
         need_device(tables[i], "bf16 split table");
         TORCH_CHECK(tables[i].scalar_type() == at::kBFloat16, "d3pm_mi355x: bf16 split tables are bfloat16");
-        need_numel(tables[i], T * 3 * K * K, "bf16 split table (bfloat16 [T, 3, K / 8, K, 8])");
+        need_numel(tables[i], T * 3 * K * K, "bf16 split table (bfloat16 [T, K / 32, K / 16, 3, 64, 8])");
       }
     }
   }
@@ -505,12 +505,14 @@ Tensor table_to_f32(const Tensor& table) {
 }
 
 // a contiguous float32 [T,K,K] table as three bf16 planes (hi, mid, lo: their sum is the float32 value), laid out
-// [T, 3, K / 8, K, 8] for the bf16 matrix instructions: the operand form of _at_onehot's matmul (:242-247)
+// [T, K / 32, K / 16, 3, 64, 8] as the operand image of the bf16 matrix instructions: the operand form of
+// _at_onehot's matmul (:242-247)
 Tensor table_split_bf16x3(const Tensor& table) {
   D3PM_GUARD(table);
   TORCH_CHECK_VALUE(table.dim() == 3 && table.size(1) == table.size(2), "d3pm_mi355x: table must be [T, K, K]");
   const int64_t T = table.size(0), K = table.size(1);
-  Tensor out = at::empty({T, 3, K / 8, K, 8}, table.options().dtype(at::kBFloat16));
+  TORCH_CHECK_VALUE(K % 32 == 0, "d3pm_mi355x: the operand image needs K to be a multiple of 32");
+  Tensor out = at::empty({T, K / 32, K / 16, 3, 64, 8}, table.options().dtype(at::kBFloat16));
   check_rc(d3pm_table_split_bf16x3(f32(table, "table"), (int)T, (int)K, (uint16_t*)out.data_ptr(), stream()));
   return out;
 }

@@ -123,13 +123,16 @@ int d3pm_table_fingerprint(const double* table, long st, long sr, long sc, int T
 int d3pm_table_to_f32(const double* table, long st, long sr, long sc, int T, int K,
                       float* out, void* stream);
 
-/* A contiguous float32 [T][K][K] table (row = reduction index, column = output
- * class of the contraction it serves) as three bf16 planes whose sum is the
- * float32 value exactly: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid),
- * round to nearest.  out: bf16 [T][3][K/8][K][8] -- plane, block of eight
- * consecutive rows, column, row within the block -- 6 T K K bytes; K a multiple
- * of 8.  Serves the `a.to(float32)` + matmul of _at_onehot,
- * d3pm/diffusion_discrete.py:242-247, on the bf16 matrix instructions. */
+/* A contiguous float32 [T][K][K] table (row = reduction index k, column =
+ * output class m of the contraction it serves) as three bf16 planes whose sum
+ * is the float32 value exactly: hi = bf16(x), mid = bf16(x - hi),
+ * lo = bf16(x - hi - mid), round to nearest -- stored as the operand image of
+ * v_mfma_f32_16x16x32_bf16: bf16 [T][K/32][K/16][3][64][8] = reduction block u,
+ * output-class tile mt, piece, lane, slot, where lane (kg << 4 | mm) holds for
+ * class 16 mt + mm the reduction indices 32 u + 16 (s >> 2) + 4 kg + (s & 3),
+ * s = 0..7.  6 T K K bytes; K a multiple of 32.  Serves the `a.to(float32)` +
+ * matmul of _at_onehot, d3pm/diffusion_discrete.py:242-247, on the bf16 matrix
+ * instructions. */
 int d3pm_table_split_bf16x3(const float* table, int T, int K, uint16_t* out, void* stream);
 
 /* Float32 view of the tables a kernel needs.  `structured` selects the digest
