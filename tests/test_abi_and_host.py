@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, n), f"{n} declared in include/d3pm_hip.h but not exported"
     # and the binding lists exactly the header's functions
     assert sorted(pkg._lib.SIGNATURES) == names
-    assert pkg._lib.lib.d3pm_abi_version() == 9
+    assert pkg._lib.lib.d3pm_abi_version() == pkg._lib.ABI_VERSION == 10
 
 
 def test_torch_ops_registered(pkg):
@@ -51,8 +51,8 @@ def test_torch_ops_registered(pkg):
 
 
 def test_struct_layout_matches_header(pkg):
-    # d3pm_tables_f32: 3 ints + float + 5 pointers; d3pm_tables_f64: 2 ints + 3 pointers
-    assert ctypes.sizeof(pkg._lib.TablesF32) == 16 + 5 * 8
+    # d3pm_tables_f32: 3 ints + float + 7 pointers; d3pm_tables_f64: 2 ints + 3 pointers
+    assert ctypes.sizeof(pkg._lib.TablesF32) == 16 + 7 * 8
     assert ctypes.sizeof(pkg._lib.TablesF64) == 8 + 3 * 8
 
 
