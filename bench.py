@@ -936,7 +936,7 @@ def main(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--compat", action="store_true",
                     help="time training_losses(...).mean().backward() instead of the two-launch training_step")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
+    ap.add_argument("--steps-per-graph", type=int, default=16,
                     help="consecutive steps captured in one HIP graph (a graph launch costs ~19 us of host time: with one "
                          "step per graph the host, not the GPU, bounds the step rate)")
     ap.add_argument("--no-pipeline", action="store_true",
