@@ -98,6 +98,27 @@ def main():
                                                                              ptr(t_out), ptr(xt_out), sp)),
                   16 * B * L, "d3pm_q_sample_draw_t (timestep draw + corruption, device noise), 16 B/token")
 
+    # ---- structured tables with wide alphabets (uniform transitions on 6- to 8-bit data): k_hybrid_loss_wide<K / 16>
+    for bits in (6, 7, 8):
+        KW = 2 ** bits
+        if only and f"hybrid_wide{KW}" not in only:
+            continue
+        dw = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type="uniform", num_bits=bits, transition_bands=None,
+                                        model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                        hybrid_coeff=lam, device=dev)
+        tbw = dw.tables()
+        x0w = torch.randint(0, KW, (B, L, 1, 1), device=dev)
+        xtw = dw.q_sample(x0w, t)
+        lgw = torch.randn(B, L, 1, 1, KW, device=dev)
+        dlw = torch.empty_like(lgw)
+        wsbw = lib.d3pm_hybrid_loss_workspace(B, L, KW)
+        wsw = torch.empty(max(wsbw // 4, 1), device=dev)
+        timed(f"hybrid_wide{KW}", lambda: check(lib.d3pm_hybrid_loss(
+            tbw.desc(), ptr(lgw), KW, ptr(x0w), 8, ptr(xtw), 8, ptr(t), 4, B, L, LOSS["hybrid"], lam, 1.0 / B, None, None,
+            None, ptr(loss), ptr(dlw), None, None, 0, ptr(wsw), wsbw, sp)),
+            (8 * KW + 16) * B * L, f"d3pm_hybrid_loss fwd+bwd, uniform Q, K={KW}, 8K+16 B/token")
+        del lgw, dlw
+
     # ---- protein-style: B=256, L=512, K=22, n_tokens=24; reverse step at 1250 x 263, n_tokens=22
     tok = d3pm_amd.Tokenizer()
     Qb, Qt = tok.q_uniform_schedule(num_steps=500, device=dev)
