@@ -701,7 +701,7 @@ def worker(args):
         dms = event_ms(dense_only, 100, warm=20)
         tfl = 4.0 * KI * KI * BI * LI / (dms * 1e-3) / 1e12
         # the same launch on the float32 matrix instructions (dense_matmul='f32'): the exact-float32 contraction the
-        # default emulates with three bf16 pieces per operand and six products per term
+        # default emulates with two float16 pieces per operand and three products per term
         from d3pm_amd.tables import ImageTables
         tbf = ImageTables(di.q_mats, di.transpose_q_onestep_mats, eps=di.eps, transposed_onestep=True, dense_matmul="f32")
 
@@ -716,11 +716,11 @@ def worker(args):
                  "kernel_ms": dms, "tokens_per_s": BI * LI / (dms * 1e-3),
                  "roofline": {"bound": "mfma", "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
                               "flops_per_token": 4 * KI * KI,
-                              "dtype": "f32 emulated on the bf16 matrix pipe: operands split into three bf16 pieces, six "
-                                       "v_mfma_f32_16x16x32_bf16 products per term (relative error < 2^-22 per product); "
+                              "dtype": "f32 emulated on the float16 matrix pipe: operands scaled and split into two float16 pieces, three "
+                                       "v_mfma_f32_16x16x32_f16 products per term (relative error < 2^-22 per product); "
                                        "achieved / peak are algorithmic float32 flops against the float32 MFMA peak",
-                              "executed_bf16_tflops": 6 * tfl, "executed_peak_bf16": 2500.0,
-                              "executed_frac_of_bf16_peak": 6 * tfl / 2500.0},
+                              "executed_f16_tflops": 3 * tfl, "executed_peak_f16": 2500.0,
+                              "executed_frac_of_f16_peak": 3 * tfl / 2500.0},
                  "f32_matrix_instructions": {"what": "dense_matmul='f32': v_mfma_f32_32x32x2_f32, an in-order float32 fma chain",
                                              "kernel_ms": fms, "achieved": tflf, "peak": 157.3, "frac": tflf / 157.3}}
         if not args.no_cpu_baseline and world == 1:

@@ -25,8 +25,8 @@ LOSS = {"kl": 0, "cross_entropy_x_start": 1, "hybrid": 2}
 class TablesF32(C.Structure):
     _fields_ = [("K", C.c_int), ("T", C.c_int), ("structured", C.c_int), ("eps", C.c_float),
                 ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p), ("qbar", C.c_void_p),
-                ("qoneT", C.c_void_p), ("qbarT", C.c_void_p), ("qbar_bf16x3", C.c_void_p),
-                ("qbarT_bf16x3", C.c_void_p)]
+                ("qoneT", C.c_void_p), ("qbarT", C.c_void_p), ("qbar_f16x2", C.c_void_p),
+                ("qbarT_f16x2", C.c_void_p)]
 
 
 class TablesF64(C.Structure):
@@ -48,7 +48,7 @@ SIGNATURES = {
     "d3pm_digest_f64": (_I, [_P, _L, _L, _L, _I, _I, _D, _P, _P, _P]),
     "d3pm_table_fingerprint": (_I, [_P, _L, _L, _L, _I, _I, _P, _P]),
     "d3pm_table_to_f32": (_I, [_P, _L, _L, _L, _I, _I, _P, _P]),
-    "d3pm_table_split_bf16x3": (_I, [_P, _I, _I, _P, _P]),
+    "d3pm_table_split_f16x2": (_I, [_P, _I, _I, _P, _P]),
     "d3pm_q_probs": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _P]),
     "d3pm_q_sample": (_I, [_T32, _P, _I, _P, _I, _I, _L, _P, _I, _U64, _U64, _P, _P, _P]),
     "d3pm_q_posterior_logits": (_I, [_T32, _P, _I, _L, _I, _P, _I, _P, _I, _I, _L, _P, _P]),

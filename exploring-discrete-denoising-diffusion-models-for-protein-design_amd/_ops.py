@@ -24,7 +24,7 @@ ops = torch.ops.d3pm_mi355x
 OP_NAMES = ("q_probs", "q_sample", "q_sample_draw_t", "q_posterior_logits", "q_posterior_logits_backward", "hybrid_loss",
             "hybrid_loss_step", "hybrid_loss_then_q_sample", "hybrid_loss_static_", "scale_rows_", "p_sample", "prior_bpd",
             "logistic_logits", "logistic_logits_backward", "build_tables", "protein_uniform_tables", "cumprod",
-            "digest_f32", "digest_f64", "table_to_f32", "table_split_bf16x3", "table_fingerprints", "lvb_digest", "lvb_loss", "lvb_hybrid_loss", "lvb_reverse_step", "corrupt")
+            "digest_f32", "digest_f64", "table_to_f32", "table_split_f16x2", "table_fingerprints", "lvb_digest", "lvb_loss", "lvb_hybrid_loss", "lvb_reverse_step", "corrupt")
 
 
 def i64(x: int) -> int:

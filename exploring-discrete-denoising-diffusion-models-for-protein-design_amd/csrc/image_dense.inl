@@ -278,41 +278,39 @@ __device__ __forceinline__ void tile_contract_mfma256(const float* __restrict__ 
       }
 }
 
-// The same contraction with float32 emulated on the bf16 matrix cores, which on this part run at sixteen times the
-// float32 matrix rate.  Every float32 operand is the exact sum of three bf16 values (x = hi + mid + lo, each the
-// round-to-nearest bf16 of what the ones before it left: 3 x 8 significant bits), so a product is the sum of nine
-// bf16 x bf16 products, each of them exact in the float32 accumulator; the six of magnitude 2^-16 |x y| and above
-// are issued (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi), the three left out are below 2^-23 |x y| together --
-// the size of the float32 rounding the plain contraction makes on every accumulation step.  v_mfma_f32_32x32x16_bf16
-// takes 32 cycles: six per 16 reduction steps against eight 64-cycle v_mfma_f32_32x32x2_f32, 192 cycles against 512.
-// The table arrives pre-split (d3pm_table_split_bf16x3: a lane's operand of eight reduction indices for one output
-// class is one 16-byte piece); the LDS rows stay float32 and every wave splits the row pieces it reads (about 4.5
-// vector operations per element).  Waves, output tiles and the C layout are those of tile_contract_mfma256.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The same contraction with float32 emulated on the 16-bit matrix instructions, which on this part run at sixteen times
+// the float32 matrix rate.  An operand x, scaled by a power of two into float16's range, is split into two float16
+// pieces: hi = x rounded towards zero (11 significant bits), lo = float16 of the exact remainder x - hi (11 more bits
+// wherever the remainder is a normal float16, an absolute 2^-25 of the scale below that).  Of the four piece products
+// three are issued (lo hi', hi lo', hi hi': each exact in the float32 accumulator); lo lo' is below 2^-22 |x y|, about
+// four float32 roundings, where an in-order float32 fma chain makes one rounding on each of its 256 steps.  Scales:
+// table entries and softmax probabilities are at most 1 and carry 2^14 (an entry below 2^-39 is lost: against the eps
+// = 1e-6 that every contracted value is added to before its logarithm, 2e-6 relative in the worst case); the backward
+// operand d loss / d f2 carries a power of two per token that puts its largest element into [2^13, 2^14).
+// v_mfma_f32_32x32x16_f16 takes 32 cycles: three per 16 reduction steps against eight 64-cycle v_mfma_f32_32x32x2_f32,
+// 96 matrix-pipe cycles against 512.
+// The table arrives pre-split (d3pm_table_split_f16x2: a lane's operand of eight reduction indices for one output
+// class is one 16-byte piece); the LDS rows stay float32 and every wave splits the row pieces it reads.  Waves, output
+// tiles and the C layout are those of tile_contract_mfma256.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned bf16_pair(float a, float b) {        // v_cvt_pk_bf16_f32: a in the low half
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// eight consecutive floats -> their hi / mid / lo bf16 operands
-__device__ __forceinline__ void split_bf16x3(const float4& p, const float4& q, u32x4& hi, u32x4& mid, u32x4& lo) {
+// eight floats (already scaled into float16's range) -> their hi / lo float16 operands: hi = the value rounded towards
+// zero, lo = float16 of the exact remainder
+__device__ __forceinline__ void split_f16x2(const float4& p, const float4& q, u32x4& hi, u32x4& lo) {
   const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = x[2 * i], b = x[2 * i + 1];
-    const unsigned h = bf16_pair(a, b);
-    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);   // exact
-    const unsigned m = bf16_pair(ra, rb);
-    const float la = ra - __builtin_bit_cast(float, m << 16), lb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
-    hi[i] = h; mid[i] = m; lo[i] = bf16_pair(la, lb);
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    hi[i] = __builtin_bit_cast(unsigned, h);
+    lo[i] = __builtin_bit_cast(unsigned, l);
   }
 }
 
 template <int TM>
-__device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict__ Ms, const float* in, float* out) {
+__device__ __forceinline__ void tile_contract_f16x2(const uint16_t* __restrict__ Ms, const float* in, float* out) {
   constexpr int K = 256, LDK = K + 4, RT = TM / 32, NC = K / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -323,20 +321,20 @@ __device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict_
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.0f;
-  // Operand image (d3pm_table_split_bf16x3): piece p of (reduction block u, class tile mt, lane kg << 4 | mm) at byte
-  // ((u 16 + mt) 3 + p) 1024 + (kg 16 + mm) 16, holding reduction indices 32 u + 16 (s >> 2) + 4 kg + (s & 3).
+  // Operand image (d3pm_table_split_f16x2): piece p of (reduction block u, class tile mt, lane kg << 4 | mm) at byte
+  // ((u 16 + mt) 2 + p) 1024 + (kg 16 + mm) 16, holding reduction indices 32 u + 16 (s >> 2) + 4 kg + (s & 3).
   // Step c of lane half h takes (u, kg) = (c >> 1, 2 (c & 1) + h); its output class is 64 wave + 32 ct + r.
   const __amdgpu_buffer_rsrc_t Mrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ms), 0, 3 * K * K * 2, 0x00020000);
-  const int boff = (4 * wave + (r >> 4)) * 3072 + h * 256 + (r & 15) * 16;
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Ms), 0, 2 * K * K * 2, 0x00020000);
+  const int boff = (4 * wave + (r >> 4)) * 2048 + h * 256 + (r & 15) * 16;
   const float* arow = in + (size_t)r * LDK + 4 * h;
-  auto load_b = [&](u32x4 (&b)[3][2], int c) {
+  auto load_b = [&](u32x4 (&b)[2][2], int c) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
         b[s][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            Mrs, boff + s * 1024, (c >> 1) * 49152 + (c & 1) * 512 + ct * 6144, 0));
+            Mrs, boff + s * 1024, (c >> 1) * 32768 + (c & 1) * 512 + ct * 4096, 0));
   };
   auto load_a = [&](float4 (&av)[RT][2], int c) {
 #pragma unroll
@@ -346,19 +344,16 @@ __device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict_
         av[rt][f] = *reinterpret_cast<const float4*>(arow + (size_t)rt * 32 * LDK + 32 * (c >> 1) + 8 * (c & 1) + 16 * f);
   };
   auto mm = [&](f32x16& d, const u32x4& x, const u32x4& y) {
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), d, 0, 0, 0);
   };
-  auto compute = [&](const float4 (&av)[RT][2], const u32x4 (&b)[3][2]) {
+  auto compute = [&](const float4 (&av)[RT][2], const u32x4 (&b)[2][2]) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      u32x4 ah, am, al;
-      split_bf16x3(av[rt][0], av[rt][1], ah, am, al);
+      u32x4 ah, al;
+      split_f16x2(av[rt][0], av[rt][1], ah, al);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {      // small terms first
         mm(acc[rt][ct], al, b[0][ct]);
-        mm(acc[rt][ct], am, b[1][ct]);
-        mm(acc[rt][ct], ah, b[2][ct]);
-        mm(acc[rt][ct], am, b[0][ct]);
         mm(acc[rt][ct], ah, b[1][ct]);
         mm(acc[rt][ct], ah, b[0][ct]);
       }
@@ -368,7 +363,7 @@ __device__ __forceinline__ void tile_contract_bf16x3(const uint16_t* __restrict_
   // matrix instructions x 32 cycles of cover); the LDS row pieces are read one step ahead.
   constexpr int NB = 2;      // measured: a ring of four spills (210 registers) and is 18 % slower
   static_assert(NC % NB == 0, "the ring is unrolled over whole trips");
-  u32x4 b[NB][3][2];
+  u32x4 b[NB][2][2];
   float4 av[2][RT][2];
 #pragma unroll
   for (int i = 0; i < NB - 1; ++i) load_b(b[i], i);
@@ -415,7 +410,9 @@ struct DenseExtra {
 
 template <class L, int MODE, bool GRAD, int NOISE, bool MFMA, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, DenseExtra e) {
-  static_assert(MFMA || !SPLIT, "the bf16 split contraction is a matrix-core path");
+  static_assert(MFMA || !SPLIT, "the split contraction is a matrix-core path");
+  static_assert(!(SPLIT && GRAD), "with split tables the training form runs on k_dense_loss256");
+  constexpr float PSC = SPLIT ? 16384.0f : 1.0f;        // float16 operand pieces: pi x 2^14 into LDS, f2 = acc / 2^28
   using C = DenseCfg<L, MFMA>;
   extern __shared__ __align__(16) float lds[];
   __shared__ float red[2 * (BLOCK / 64)];
@@ -446,8 +443,8 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
   const bool need_post = (t > 0) && !(MODE == DENSE_LOSS && e.loss_type == D3PM_LOSS_CE);
   const float* Qm = need_post ? a.tb.qbar + (size_t)(t - 1) * K * K : nullptr;
   const float* QmT = (need_post && GRAD) ? a.tb.qbarT + (size_t)(t - 1) * K * K : nullptr;
-  const uint16_t* QmS = (SPLIT && need_post) ? a.tb.qbar_bf16x3 + (size_t)(t - 1) * 3 * K * K : nullptr;
-  const uint16_t* QmTS = (SPLIT && need_post && GRAD) ? a.tb.qbarT_bf16x3 + (size_t)(t - 1) * 3 * K * K : nullptr;
+  const uint16_t* QmS = (SPLIT && need_post) ? a.tb.qbar_f16x2 + (size_t)(t - 1) * 2 * K * K : nullptr;
+  const uint16_t* QmTS = nullptr;
 
   float w_vb = 0, w_ce = 0;
   if constexpr (MODE == DENSE_LOSS) {
@@ -529,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
 #pragma unroll
         for (int v = 0; v < L::V; ++v) {
           if constexpr (!MFMA) zkeep[ps][v] = z[v];
-          pn[v] = live ? pi[v] * inv : 0.0f;
+          pn[v] = live ? pi[v] * (inv * PSC) : 0.0f;
         }
         store_slots<L>(s_pi + (size_t)tok * LDK, g, K, pn);
       } else {
@@ -585,7 +582,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         // the co-resident workgroup's per-token phase issues ahead of this stream of long matrix instructions,
         // which loses next to nothing by it
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (SPLIT) tile_contract_bf16x3<C::TM>(QmS, s_pi, s_f2);
+        if constexpr (SPLIT) tile_contract_f16x2<C::TM>(QmS, s_pi, s_f2);
         else tile_contract_mfma256<C::TM>(Qm, s_pi, s_f2);
         __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
       } else tile_contract<L>(Qm, K, s_pi, s_f2);
@@ -608,7 +605,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
         if (ps + 1 < NP) gather(ps + 1);
         load_slots<L>(s_f2 + (size_t)tok * LDK, g, K, 1.0f, f2e);
 #pragma unroll
-        for (int v = 0; v < L::V; ++v) f2e[v] += eps;
+        for (int v = 0; v < L::V; ++v) f2e[v] = fmaf(f2e[v], 1.0f / (PSC * PSC), eps);
       }
       if constexpr (MFMA && !GRAD) {
         if (ps == NP - 1 && more) fetch_tile(tile0 + C::TM);
@@ -717,7 +714,7 @@ __global__ __launch_bounds__(BLOCK, MFMA ? 2 : 1) void k_dense_tile(ImgArgs a, D
       if (need_post) {
         if constexpr (MFMA) {
           __builtin_amdgcn_s_setprio(0);
-          if constexpr (SPLIT) tile_contract_bf16x3<C::TM>(QmTS, s_f2, s_gp);
+          if constexpr (SPLIT) tile_contract_f16x2<C::TM>(QmTS, s_f2, s_gp);
           else tile_contract_mfma256<C::TM>(QmT, s_f2, s_gp);
           __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
         } else tile_contract<L>(QmT, K, s_f2, s_gp);
@@ -810,13 +807,13 @@ static ImgArgs make_dense_args(const d3pm_tables_f32* tb, const void* x0, int x0
 // the caller's with the VALU contraction.
 using MfmaLayout = Layout<16, 16, true, true>;
 
-// third argument of f: 0 = VALU contraction, 1 = float32 matrix instructions, 2 = float32 emulated with three bf16
+// third argument of f: 0 = VALU contraction, 1 = float32 matrix instructions, 2 = float32 emulated with two float16
 // pieces per operand (taken when the caller built both split tables)
 template <class L, class F>
 static int with_mfma_choice(const d3pm_tables_f32* tb, F&& f) {
   if constexpr (L::VEC) {
     if (tb->K == 256) {
-      if (tb->qbar_bf16x3 && tb->qbarT_bf16x3) return f(MfmaLayout{}, std::integral_constant<int, 2>{});
+      if (tb->qbar_f16x2 && tb->qbarT_f16x2) return f(MfmaLayout{}, std::integral_constant<int, 2>{});
       return f(MfmaLayout{}, std::integral_constant<int, 1>{});
     }
   }

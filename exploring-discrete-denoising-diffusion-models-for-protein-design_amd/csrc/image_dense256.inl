@@ -9,7 +9,7 @@
 // per-class array.  In that order
 //   * a token's row is read and written as sixteen 16-byte pieces per lane;
 //   * the two K x K contractions run as  out^T = table-image x act^T  on
-//     v_mfma_f32_16x16x32_bf16 with the table as the A operand (rows = output
+//     v_mfma_f32_16x16x32_f16 with the table as the A operand (rows = output
 //     classes) and the wave's activations as the B operand (columns = tokens):
 //     accumulator tile mt of the result is element (mt, .) of the output array,
 //     and elements (2u, .), (2u+1, .) of an input array are the B operand of
@@ -17,22 +17,24 @@
 //     -> softmax backward never leave the lane's registers;
 //   * sums over a token's classes are 63 additions in registers and two
 //     cross-lane steps (lanes tok, tok + 16, tok + 32, tok + 48).
-// float32 is emulated on the bf16 matrix pipe as in tile_contract_bf16x3 (three
-// pieces per operand, six products); the activations are split once per use by
-// the wave that owns them.  The table (d3pm_table_split_bf16x3's operand image,
-// 384 KB per timestep and orientation) streams from L2 through a three-stage LDS
-// ring of 24 KB stages shared by the workgroup's four waves, one barrier per
-// stage; a stage is 8 output-class tiles x 3 pieces x 1 KB, byte for byte the
+// float32 is emulated on the float16 matrix pipe as in tile_contract_f16x2 (two
+// pieces per operand, three products); the activations are split once per use
+// by the wave that owns them.  The table (d3pm_table_split_f16x2's operand image,
+// 256 KB per timestep and orientation) streams from L2 through a four-stage LDS
+// ring of 16 KB stages shared by the workgroup's four waves, one barrier per
+// stage; a stage is 8 output-class tiles x 2 pieces x 1 KB, byte for byte the
 // image in global memory, and a wave's A-operand read is 1 KB of consecutive
-// bytes (no bank conflicts).  72 KB of LDS and at most 256 registers: two
+// bytes (no bank conflicts).  64 KB of LDS and at most 256 registers: two
 // workgroups per CU, one's per-token arithmetic under the other's contraction.
 
 namespace d3pm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RT_STAGE = 8 * 3 * 1024;        // bytes of one ring stage
-constexpr int RT_TABLE = 3 * 256 * 256 * 2;   // bytes of one timestep's operand image
+constexpr int RT_STAGE = 8 * 2 * 1024;        // bytes of one ring stage
+constexpr int RT_RING = 4;                     // stages in the LDS ring
+constexpr int RT_TABLE = 2 * 256 * 256 * 2;   // bytes of one timestep's operand image
+constexpr float RT_SCALE = 16384.0f;          // 2^14: what the table image and the forward activations are scaled by
 
 __device__ __forceinline__ float quad_lanes_sum(float x) {      // over lanes tok, tok+16, tok+32, tok+48
   x += __shfl_xor(x, 16);
@@ -57,45 +59,53 @@ __device__ __forceinline__ void ring_dma(const __amdgpu_buffer_rsrc_t& trs, char
   int off;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(off));
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % 3) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
+  for (int i = 0; i < RT_STAGE / 4096; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % RT_RING) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
                                              s * RT_STAGE + i * 4096 + wave * 1024, 0, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const char* table) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, RT_TABLE, 0x00020000);
 }
-// Requests the first two stages of `table`.  Call once every wave of the workgroup is past its last read of the
+// Requests the first three stages of `table`.  Call once every wave of the workgroup is past its last read of the
 // ring (regtile_contract ends with a barrier), as early as the table is known: the stages arrive under whatever the
 // waves do until the contraction.
 __device__ __forceinline__ void ring_begin(const char* table, char* ring) {
   const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
   ring_dma(trs, ring, 0);
   ring_dma(trs, ring, 1);
+  ring_dma(trs, ring, 2);
+}
+// Barrier of the ring: waits until all but the wave's `pending` most recent DMA instructions have landed (and its
+// LDS reads have returned), then meets the other waves.  Not __syncthreads(): its fence waits for every DMA.
+template <int PENDING>
+__device__ __forceinline__ void ring_barrier() {
+  if constexpr (PENDING == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
 // out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all 256 classes of `act` taking
 // part (act in element order).  Every wave of the workgroup calls this together, after ring_begin(table).
 //
-// The contraction is a flat sequence of 128 blocks (reduction block u, class tile mt): three 1 KB piece reads and
-// six matrix instructions each.  Stage s = blocks 8 s .. 8 s + 7 sits in ring buffer s % 3; its DMA is issued at the
-// start of stage s - 2 (its buffer's previous content, stage s - 3, was last read before the barrier that ends that
-// stage), waited for and published by the barrier at the end of stage s - 2, and read from the end of stage s - 1
-// on: the piece reads run two blocks ahead of the matrix instructions and cross the stage boundaries, so neither a
-// barrier nor an LDS latency sits between two stages' matrix instructions.
+// The contraction is a flat sequence of 128 blocks (reduction block u, class tile mt): two 1 KB piece reads and
+// three matrix instructions each.  Stage s = blocks 8 s .. 8 s + 7 sits in ring buffer s % 4; its DMA is issued at
+// the start of stage s - 3 (its buffer's previous content, stage s - 4, was last read before the barrier that ends
+// that stage), must have landed at the barrier that ends stage s - 2 (which waits for all but the most recent
+// stage's DMA instructions: two stages of cover) and is read from the end of stage s - 1 on: the piece reads run two
+// blocks ahead of the matrix instructions and cross the stage boundaries, so neither a barrier nor an LDS latency
+// sits between two stages' matrix instructions.
 __device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring, const f32x4 (&act)[16],
                                                  f32x4 (&out)[16]) {
   const int lane = threadIdx.x & 63;
   const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
   auto mm = [&](f32x4& d, const u32x4& x, const u32x4& y) {
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), d, 0, 0, 0);
   };
-  struct Frag { u32x4 hi, mid, lo; };
+  struct Frag { u32x4 hi, lo; };
   auto read_frag = [&](int j) {       // block j = 8 s + ml
-    const char* st = ring + ((j >> 3) % 3) * RT_STAGE + (j & 7) * 3072 + lane * 16;
+    const char* st = ring + ((j >> 3) % RT_RING) * RT_STAGE + (j & 7) * 2048 + lane * 16;
     Frag f;
     f.hi = *reinterpret_cast<const u32x4*>(st);
-    f.mid = *reinterpret_cast<const u32x4*>(st + 1024);
-    f.lo = *reinterpret_cast<const u32x4*>(st + 2048);
+    f.lo = *reinterpret_cast<const u32x4*>(st + 1024);
     return f;
   };
   // what the caller computed for `act` is complete here: left free, the compiler sinks the producers of act's
@@ -107,18 +117,18 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int mt = 0; mt < 16; ++mt) out[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  __syncthreads();          // stages 0 and 1 have landed (the barrier's fence waits for the DMA) and are visible
+  ring_barrier<RT_STAGE / 4096>();       // stages 0 and 1 have landed and are visible; stage 2 may be on its way
   __builtin_amdgcn_s_setprio(0);     // the co-resident workgroup's per-token arithmetic issues ahead of this stream
   Frag fr[3];
   fr[0] = read_frag(0);
   fr[1] = read_frag(1);
   // the activations' pieces of reduction block u + 1 are formed in the middle of block u's second stage, pinned
-  // there by scheduling fences (36 vector operations that issue under the matrix instructions around them); left
+  // there by scheduling fences (some twenty vector operations that issue under the matrix instructions around them); left
   // free, the compiler forms all eight blocks' pieces ahead of the loop and spills them
-  struct Pieces { u32x4 hi, mid, lo; };
+  struct Pieces { u32x4 hi, lo; };
   Pieces pc[2];
   __builtin_amdgcn_sched_barrier(0);
-  split_bf16x3(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].mid, pc[0].lo);
+  split_f16x2(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].lo);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -126,7 +136,7 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int s = 2 * u + half;
-      if (s + 2 < 16) ring_dma(trs, ring, s + 2);
+      if (s + 3 < 16) ring_dma(trs, ring, s + 3);
 #pragma unroll
       for (int ml = 0; ml < 8; ++ml) {
         const int j = 8 * s + ml;
@@ -135,19 +145,18 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
         const Frag& f = fr[j % 3];
         f32x4& d = out[8 * half + ml];
         mm(d, f.lo, b.hi);      // small terms first
-        mm(d, f.mid, b.mid);
         mm(d, f.hi, b.lo);
-        mm(d, f.mid, b.hi);
-        mm(d, f.hi, b.mid);
         mm(d, f.hi, b.hi);
         __builtin_amdgcn_sched_barrier(0);
         if (half == 1 && ml == 3 && u + 1 < 8) {
           Pieces& nx = pc[(u + 1) & 1];
-          split_bf16x3(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.mid, nx.lo);
+          split_f16x2(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.lo);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
+      // stage s + 2 has landed (the piece reads reach it before the next barrier); stage s + 3 may be in flight
+      if (s + 3 < 16) ring_barrier<RT_STAGE / 4096>();
+      else ring_barrier<0>();
     }
   }
   __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
@@ -169,9 +178,9 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
   const int tok = lane & 15, kg = lane >> 4;
   const int t = __builtin_amdgcn_readfirstlane(load_index(a.t, b, a.t_bytes, a.tb.T));
   const bool need_post = (t > 0) && e.loss_type != D3PM_LOSS_CE;
-  const char* tableF = need_post ? reinterpret_cast<const char*>(a.tb.qbar_bf16x3) + (size_t)(t - 1) * RT_TABLE : nullptr;
+  const char* tableF = need_post ? reinterpret_cast<const char*>(a.tb.qbar_f16x2) + (size_t)(t - 1) * RT_TABLE : nullptr;
   const char* tableB =
-      (need_post && GRAD) ? reinterpret_cast<const char*>(a.tb.qbarT_bf16x3) + (size_t)(t - 1) * RT_TABLE : nullptr;
+      (need_post && GRAD) ? reinterpret_cast<const char*>(a.tb.qbarT_f16x2) + (size_t)(t - 1) * RT_TABLE : nullptr;
   const float gb = e.grad_scale * ((GRAD && e.grad_out) ? e.grad_out[b] : 1.0f);
   const float cnorm = gb / ((float)a.npos * LN2);
   const float w_vb = (e.loss_type == D3PM_LOSS_CE) ? 0.0f : cnorm;
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
     sum = quad_lanes_sum(sum);
     const float inv = fast_rcp(sum);
     const float ce = fmaf(fast_log2(sum), LN2, m) - zx0;
-    const float pscale = live ? inv : 0.0f;
+    const float pscale = live ? inv * RT_SCALE : 0.0f;      // the contraction's operand: pi x 2^14 (float16 pieces)
 #pragma unroll
     for (int mt = 0; mt < 16; ++mt) v[mt] *= pscale;
     float vb = ce;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f2[mt][r] += eps;
+          f2[mt][r] = fmaf(f2[mt][r], 1.0f / (RT_SCALE * RT_SCALE), eps);
           zm = fmaf(av[mt][r], f2[mt][r], zm);
           zt = fmaf(av[mt][r], bv[mt][r], zt);
         }
@@ -271,6 +280,22 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
         }
       vb = quad_lanes_sum(kl) * izt * LN2;
       D3PM_PHASE256(3);
+      float unscale = 0;
+      if constexpr (GRAD) {
+        // the token's d loss / d f2 row scaled by a power of two into [2^13, 2^14): float16 pieces keep 22
+        // significant bits of the largest elements and an absolute 2^-39 of that scale below
+        float mx = 0;
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(f2[mt][r]));
+        mx = quad_lanes_max(mx);
+        const int ex = max(-80, min(80, __builtin_amdgcn_frexp_expf(mx)));       // mx = m 2^ex, m in [0.5, 1)
+        const float sc = __builtin_ldexpf(1.0f, 14 - ex);
+        unscale = __builtin_ldexpf(1.0f, ex - 28);                                // 1 / (sc x 2^14)
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) f2[mt] *= sc;
+      }
       if constexpr (GRAD) {
         // ---- d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T, then through the softmax (re-formed from the
         // re-read row with the same max and 1 / sum: bit-identical) plus the cross-entropy term
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             pi[mt][r] = fast_exp2((z[r] - m) * LOG2E) * inv;
+            gp[mt][r] *= unscale;
             dot = fmaf(pi[mt][r], gp[mt][r], dot);
           }
         }
@@ -325,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
           const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
           f32x4 gz;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gz[r] = fmaf(-hit, sel[r], w * v[mt][r]);
+          for (int r = 0; r < 4; ++r) gz[r] = fmaf(-hit, sel[r], (w / RT_SCALE) * v[mt][r]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gz), grs, rowoff + 64 * mt, 0, 0);
         }
       }
@@ -354,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
 
 static int launch_loss256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   auto kern = k_dense_loss256<true>;
-  const int sh = 3 * RT_STAGE;
+  const int sh = RT_RING * RT_STAGE;
   hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   DenseExtra ee = e;

@@ -237,17 +237,17 @@ __global__ void k_cast_f32(const double* __restrict__ table, long st, long sr, l
   }
 }
 
-// float32 [T][K][K] (row = reduction index k, column = output class m) -> the operand image of the bf16 matrix
-// instructions, [T][K/32][K/16][3][64][8] bf16: reduction block u, output-class tile mt, piece p (hi, mid, lo), lane,
+// float32 [T][K][K] (row = reduction index k, column = output class m) -> the operand image of the float16 matrix
+// instructions, [T][K/32][K/16][2][64][8] float16: reduction block u, output-class tile mt, piece p (hi, lo), lane,
 // slot.  Lane l = (kg << 4) | mm holds, for output class 16 mt + mm, the eight reduction indices
-// k = 32 u + 16 (s >> 2) + 4 kg + (s & 3), s = 0..7 -- the A operand of v_mfma_f32_16x16x32_bf16 (row = lane & 15,
+// k = 32 u + 16 (s >> 2) + 4 kg + (s & 3), s = 0..7 -- the A operand of v_mfma_f32_16x16x32_f16 (row = lane & 15,
 // reduction group = lane >> 4) under a reduction order in which a lane's eight indices are two runs of four
 // consecutive classes 16 apart: the order the accumulator tiles of a previous 16x16 product hold their rows in, so
-// that a result can be the next product's operand without leaving its registers.  x = hi + mid + lo exactly, each
-// piece the round-to-nearest bf16 of what the ones before it left (the two subtractions are exact in float32).
-// One thread per (u, mt, lane): eight strided reads, three 16-byte writes; consecutive threads write consecutive
+// that a result can be the next product's operand without leaving its registers.  The pieces are those of 2^14 x
+// (entries are probabilities: at most 1): hi = float16(2^14 x), lo = float16(2^14 x - hi), round to nearest.
+// One thread per (u, mt, lane): eight strided reads, two 16-byte writes; consecutive threads write consecutive
 // 16-byte pieces.
-__global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ table, int K, uint16_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_split_f16x2(const float* __restrict__ table, int K, uint16_t* __restrict__ out) {
   const int t = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;       // (u * (K / 16) + mt) * 64 + lane
   if (e >= (K / 32) * (K / 16) * 64) return;
@@ -255,21 +255,18 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float* __restrict__ 
   const int mt = um % (K / 16), u = um / (K / 16);
   const int mm = lane & 15, kg = lane >> 4;
   const float* m = table + (size_t)t * K * K + 16 * mt + mm;
-  uint16_t h[8], md[8], lo[8];
+  uint16_t h[8], lo[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int k = 32 * u + 16 * (s >> 2) + 4 * kg + (s & 3);
-    const float x = m[(size_t)k * K];
-    const __bf16 xh = (__bf16)x;
-    const float r1 = x - (float)xh;
-    const __bf16 xm = (__bf16)r1;
-    const float r2 = r1 - (float)xm;
-    const __bf16 xl = (__bf16)r2;
-    h[s] = __builtin_bit_cast(uint16_t, xh); md[s] = __builtin_bit_cast(uint16_t, xm); lo[s] = __builtin_bit_cast(uint16_t, xl);
+    const float x = m[(size_t)k * K] * 16384.0f;            // entries are probabilities: 2^14 x fits float16
+    const _Float16 xh = (_Float16)x;
+    const _Float16 xl = (_Float16)(x - (float)xh);
+    h[s] = __builtin_bit_cast(uint16_t, xh); lo[s] = __builtin_bit_cast(uint16_t, xl);
   }
-  uint16_t* o = out + (size_t)t * 3 * K * K + ((size_t)um * 3 * 64 + lane) * 8;
+  uint16_t* o = out + (size_t)t * 2 * K * K + ((size_t)um * 2 * 64 + lane) * 8;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) { o[s] = h[s]; o[64 * 8 + s] = md[s]; o[2 * 64 * 8 + s] = lo[s]; }
+  for (int s = 0; s < 8; ++s) { o[s] = h[s]; o[64 * 8 + s] = lo[s]; }
 }
 
 // 64-bit content fingerprint of a strided [T,K,K] float64 table: the sum, modulo 2^64, of every element's bit
@@ -383,11 +380,11 @@ extern "C" int d3pm_table_to_f32(const double* table, long st, long sr, long sc,
   return D3PM_OK;
 }
 
-extern "C" int d3pm_table_split_bf16x3(const float* table, int T, int K, uint16_t* out, void* stream) {
+extern "C" int d3pm_table_split_f16x2(const float* table, int T, int K, uint16_t* out, void* stream) {
   D3PM_CHECK_ARG(table && out && T >= 1, "null pointer or empty table");
   D3PM_CHECK_ARG(K >= 32 && K % 32 == 0, "the operand image needs K to be a multiple of 32, got %d", K);
   const int n = (K / 32) * (K / 16) * 64;
-  hipLaunchKernelGGL(k_split_bf16x3, dim3((n + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, table, K, out);
-  D3PM_LAUNCH_CHECK("k_split_bf16x3");
+  hipLaunchKernelGGL(k_split_f16x2, dim3((n + 255) / 256, T), dim3(256), 0, (hipStream_t)stream, table, K, out);
+  D3PM_LAUNCH_CHECK("k_split_f16x2");
   return D3PM_OK;
 }

@@ -76,7 +76,7 @@ int64_t need_rows(const Tensor& rows, int B, long npos, int64_t K, const char* w
 }
 void need_image_tables(at::TensorList tables, int64_t K, int64_t T, bool structured) {
   TORCH_CHECK(tables.size() == 5 || tables.size() == 7,
-              "d3pm_mi355x: tables = [qbar_digest, qone_digest, qbar, qoneT, qbarT(, qbar_bf16x3, qbarT_bf16x3)]");
+              "d3pm_mi355x: tables = [qbar_digest, qone_digest, qbar, qoneT, qbarT(, qbar_f16x2, qbarT_f16x2)]");
   TORCH_CHECK_VALUE(K >= 2 && K <= 256 && T >= 1, "d3pm_mi355x: need 2 <= K <= 256 and T >= 1");
   need_numel(tables[0], T * 8 * K, "qbar_digest (float32 [T, 8, K])");
   need_numel(tables[1], T * 8 * K, "qone_digest (float32 [T, 8, K])");
@@ -84,13 +84,13 @@ void need_image_tables(at::TensorList tables, int64_t K, int64_t T, bool structu
     for (int i = 2; i < 5; ++i) need_numel(tables[i], T * K * K, "dense table copy (float32 [T, K, K])");
   if (tables.size() == 7) {
     const bool h0 = tables[5].defined() && tables[5].numel() > 0, h1 = tables[6].defined() && tables[6].numel() > 0;
-    TORCH_CHECK_VALUE(h0 == h1, "d3pm_mi355x: the bf16 split tables come as a pair (qbar_bf16x3, qbarT_bf16x3)");
+    TORCH_CHECK_VALUE(h0 == h1, "d3pm_mi355x: the float16 split tables come as a pair (qbar_f16x2, qbarT_f16x2)");
     if (h0) {
-      TORCH_CHECK_VALUE(!structured && K == 256, "d3pm_mi355x: bf16 split tables serve dense tables with K = 256");
+      TORCH_CHECK_VALUE(!structured && K == 256, "d3pm_mi355x: float16 split tables serve dense tables with K = 256");
       for (int i = 5; i < 7; ++i) {
-        need_device(tables[i], "bf16 split table");
-        TORCH_CHECK(tables[i].scalar_type() == at::kBFloat16, "d3pm_mi355x: bf16 split tables are bfloat16");
-        need_numel(tables[i], T * 3 * K * K, "bf16 split table (bfloat16 [T, K / 32, K / 16, 3, 64, 8])");
+        need_device(tables[i], "float16 split table");
+        TORCH_CHECK(tables[i].scalar_type() == at::kHalf, "d3pm_mi355x: split tables are float16");
+        need_numel(tables[i], T * 2 * K * K, "split table (float16 [T, K / 32, K / 16, 2, 64, 8])");
       }
     }
   }
@@ -109,8 +109,8 @@ std::vector<int64_t> with_k(const Tensor& tokens, int64_t K) {
   return s;
 }
 
-// tables = [qbar_digest, qone_digest, qbar, qoneT, qbarT(, qbar_bf16x3, qbarT_bf16x3)]; all but the digests may be
-// empty tensors (structured tables; no bf16 split tables: the float32 matrix instructions serve K = 256)
+// tables = [qbar_digest, qone_digest, qbar, qoneT, qbarT(, qbar_f16x2, qbarT_f16x2)]; all but the digests may be
+// empty tensors (structured tables; no float16 split tables: the float32 matrix instructions serve K = 256)
 d3pm_tables_f32 image_tables(at::TensorList tables, int64_t K, int64_t T, bool structured, double eps) {
   need_image_tables(tables, K, T, structured);
   d3pm_tables_f32 tb{};
@@ -121,8 +121,8 @@ d3pm_tables_f32 image_tables(at::TensorList tables, int64_t K, int64_t T, bool s
   tb.qbar_digest = get(0, "qbar_digest"); tb.qone_digest = get(1, "qone_digest");
   tb.qbar = get(2, "qbar"); tb.qoneT = get(3, "qoneT"); tb.qbarT = get(4, "qbarT");
   if (tables.size() == 7 && tables[5].defined() && tables[5].numel() > 0) {
-    tb.qbar_bf16x3 = (const uint16_t*)tables[5].data_ptr();
-    tb.qbarT_bf16x3 = (const uint16_t*)tables[6].data_ptr();
+    tb.qbar_f16x2 = (const uint16_t*)tables[5].data_ptr();
+    tb.qbarT_f16x2 = (const uint16_t*)tables[6].data_ptr();
   }
   return tb;
 }
@@ -504,16 +504,16 @@ Tensor table_to_f32(const Tensor& table) {
   return out;
 }
 
-// a contiguous float32 [T,K,K] table as three bf16 planes (hi, mid, lo: their sum is the float32 value), laid out
-// [T, K / 32, K / 16, 3, 64, 8] as the operand image of the bf16 matrix instructions: the operand form of
+// a contiguous float32 [T,K,K] table of probabilities as two float16 planes (hi, lo of 2^14 x the entry), laid out
+// [T, K / 32, K / 16, 2, 64, 8] as the operand image of the float16 matrix instructions: the operand form of
 // _at_onehot's matmul (:242-247)
-Tensor table_split_bf16x3(const Tensor& table) {
+Tensor table_split_f16x2(const Tensor& table) {
   D3PM_GUARD(table);
   TORCH_CHECK_VALUE(table.dim() == 3 && table.size(1) == table.size(2), "d3pm_mi355x: table must be [T, K, K]");
   const int64_t T = table.size(0), K = table.size(1);
   TORCH_CHECK_VALUE(K % 32 == 0, "d3pm_mi355x: the operand image needs K to be a multiple of 32");
-  Tensor out = at::empty({T, K / 32, K / 16, 3, 64, 8}, table.options().dtype(at::kBFloat16));
-  check_rc(d3pm_table_split_bf16x3(f32(table, "table"), (int)T, (int)K, (uint16_t*)out.data_ptr(), stream()));
+  Tensor out = at::empty({T, K / 32, K / 16, 2, 64, 8}, table.options().dtype(at::kHalf));
+  check_rc(d3pm_table_split_f16x2(f32(table, "table"), (int)T, (int)K, (uint16_t*)out.data_ptr(), stream()));
   return out;
 }
 
@@ -639,7 +639,7 @@ TORCH_LIBRARY(d3pm_mi355x, m) {
   m.def("digest_f32(Tensor table, float eps) -> (Tensor, Tensor)");
   m.def("digest_f64(Tensor table, float rtol) -> (Tensor, Tensor)");
   m.def("table_to_f32(Tensor table) -> Tensor");
-  m.def("table_split_bf16x3(Tensor table) -> Tensor");
+  m.def("table_split_f16x2(Tensor table) -> Tensor");
   m.def("table_fingerprints(Tensor[] tables) -> Tensor");
   m.def("lvb_digest(Tensor qbar_digest, Tensor qone_digest, int K, int T) -> Tensor");
   m.def("lvb_loss(" D3PM_PT "Tensor pred, Tensor x0, Tensor x_t, Tensor t, Tensor? q, int tmax, int msa, "
@@ -672,7 +672,7 @@ TORCH_LIBRARY_IMPL(d3pm_mi355x, CUDA, m) {
   m.impl("digest_f32", digest_f32);
   m.impl("digest_f64", digest_f64);
   m.impl("table_to_f32", table_to_f32);
-  m.impl("table_split_bf16x3", table_split_bf16x3);
+  m.impl("table_split_f16x2", table_split_f16x2);
   m.impl("table_fingerprints", table_fingerprints);
   m.impl("lvb_digest", lvb_digest);
   m.impl("lvb_loss", lvb_loss);

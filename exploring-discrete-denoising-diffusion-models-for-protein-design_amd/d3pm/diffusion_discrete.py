@@ -243,9 +243,9 @@ class DiscreteDiffusion:
         self._tables: Optional[ImageTables] = None
         self._tables_key = None
         self.force_dense = False
-        # how dense tables with 256 classes contract (ImageTables): 'bf16x3' = float32 emulated on the bf16 matrix
+        # how dense tables with 256 classes contract (ImageTables): 'f16x2' = float32 emulated on the float16 matrix
         # instructions, 'f32' = the float32 matrix instructions; set before the first call that uses the tables
-        self.dense_matmul = "bf16x3"
+        self.dense_matmul = "f16x2"
 
     # ------------------------------------------------------------------ tables
     def tables(self) -> ImageTables:

@@ -32,18 +32,19 @@ class ImageTables:
     anything else (Gaussian, banded) the dense path with float32 copies.
 
     ``dense_matmul`` picks how the K x K contraction of ``_at_onehot`` runs for
-    dense tables with K = 256: ``"bf16x3"`` (default) emulates float32 on the
-    bf16 matrix instructions -- every operand split into three bf16 pieces, six
-    products per term, relative error below 2^-22 per product -- from split
-    copies of the cumulative table built here (6 bytes per entry each way);
+    dense tables with K = 256: ``"f16x2"`` (default) emulates float32 on the
+    float16 matrix instructions -- every operand, scaled into float16's range,
+    split into two float16 pieces, three products per term, relative error below
+    2^-22 per product (absolute 2^-39 for entries below 2^-16) -- from split
+    copies of the cumulative table built here (4 bytes per entry each way);
     ``"f32"`` uses the float32 matrix instructions (an in-order float32 fma
     chain).  Other alphabets contract on the vector ALUs in float32 either way.
     """
 
     def __init__(self, q_mats: torch.Tensor, q_onestep: torch.Tensor, eps: float = 1e-6,
-                 transposed_onestep: bool = False, force_dense: bool = False, dense_matmul: str = "bf16x3"):
-        if dense_matmul not in ("bf16x3", "f32"):
-            raise ValueError(f"dense_matmul must be 'bf16x3' or 'f32', got {dense_matmul!r}")
+                 transposed_onestep: bool = False, force_dense: bool = False, dense_matmul: str = "f16x2"):
+        if dense_matmul not in ("f16x2", "f32"):
+            raise ValueError(f"dense_matmul must be 'f16x2' or 'f32', got {dense_matmul!r}")
         _lib.require_device(q_mats, q_onestep)
         if q_mats.dtype != torch.float64 or q_onestep.dtype != torch.float64:
             q_mats, q_onestep = q_mats.double(), q_onestep.double()
@@ -59,18 +60,18 @@ class ImageTables:
         self.qone_digest, v1 = ops.digest_f32(q_onestep, self.eps)
         self.violations = (int(v0.item()), int(v1.item()))               # one sync each, at set-up
         self.structured = (self.violations == (0, 0)) and not force_dense
-        self.qbar = self.qoneT = self.qbarT = self.qbar_bf16x3 = self.qbarT_bf16x3 = None
+        self.qbar = self.qoneT = self.qbarT = self.qbar_f16x2 = self.qbarT_f16x2 = None
         if not self.structured:
             self.qbar = ops.table_to_f32(q_mats)
             self.qbarT = ops.table_to_f32(q_mats.permute(0, 2, 1))
             self.qoneT = ops.table_to_f32(q_onestep.permute(0, 2, 1))
-            if K == 256 and dense_matmul == "bf16x3":
-                self.qbar_bf16x3 = ops.table_split_bf16x3(self.qbar)
-                self.qbarT_bf16x3 = ops.table_split_bf16x3(self.qbarT)
-        self.dense_matmul = dense_matmul if self.qbar_bf16x3 is not None else "f32"
+            if K == 256 and dense_matmul == "f16x2":
+                self.qbar_f16x2 = ops.table_split_f16x2(self.qbar)
+                self.qbarT_f16x2 = ops.table_split_f16x2(self.qbarT)
+        self.dense_matmul = dense_matmul if self.qbar_f16x2 is not None else "f32"
         self._desc = _lib.TablesF32(K, T, int(self.structured), self.eps, ptr(self.qbar_digest),
                                     ptr(self.qone_digest), ptr(self.qbar), ptr(self.qoneT), ptr(self.qbarT),
-                                    ptr(self.qbar_bf16x3), ptr(self.qbarT_bf16x3))
+                                    ptr(self.qbar_f16x2), ptr(self.qbarT_f16x2))
 
     def desc(self):
         return C.byref(self._desc)
@@ -82,8 +83,8 @@ class ImageTables:
             e = torch.empty(0, dtype=torch.float32, device=self.device)
             tabs = [self.qbar_digest, self.qone_digest, e if self.qbar is None else self.qbar,
                     e if self.qoneT is None else self.qoneT, e if self.qbarT is None else self.qbarT]
-            if self.qbar_bf16x3 is not None:
-                tabs += [self.qbar_bf16x3, self.qbarT_bf16x3]
+            if self.qbar_f16x2 is not None:
+                tabs += [self.qbar_f16x2, self.qbarT_f16x2]
             a = self._op_args = (tabs, self.K, self.T, bool(self.structured), self.eps)
         return a
 

@@ -124,16 +124,17 @@ int d3pm_table_to_f32(const double* table, long st, long sr, long sc, int T, int
                       float* out, void* stream);
 
 /* A contiguous float32 [T][K][K] table (row = reduction index k, column =
- * output class m of the contraction it serves) as three bf16 planes whose sum
- * is the float32 value exactly: hi = bf16(x), mid = bf16(x - hi),
- * lo = bf16(x - hi - mid), round to nearest -- stored as the operand image of
- * v_mfma_f32_16x16x32_bf16: bf16 [T][K/32][K/16][3][64][8] = reduction block u,
+ * output class m of the contraction it serves) of probabilities (entries in
+ * [0, 1]) as two float16 planes, hi = float16(2^14 x), lo = float16(2^14 x - hi),
+ * round to nearest: 22 significant bits of an entry of 2^-16 and above, an
+ * absolute 2^-39 below -- stored as the operand image of
+ * v_mfma_f32_16x16x32_f16: float16 [T][K/32][K/16][2][64][8] = reduction block u,
  * output-class tile mt, piece, lane, slot, where lane (kg << 4 | mm) holds for
  * class 16 mt + mm the reduction indices 32 u + 16 (s >> 2) + 4 kg + (s & 3),
- * s = 0..7.  6 T K K bytes; K a multiple of 32.  Serves the `a.to(float32)` +
- * matmul of _at_onehot, d3pm/diffusion_discrete.py:242-247, on the bf16 matrix
+ * s = 0..7.  4 T K K bytes; K a multiple of 32.  Serves the `a.to(float32)` +
+ * matmul of _at_onehot, d3pm/diffusion_discrete.py:242-247, on the float16 matrix
  * instructions. */
-int d3pm_table_split_bf16x3(const float* table, int T, int K, uint16_t* out, void* stream);
+int d3pm_table_split_f16x2(const float* table, int T, int K, uint16_t* out, void* stream);
 
 /* Float32 view of the tables a kernel needs.  `structured` selects the digest
  * path (O(K) per token) or the dense path (gathers + K x K contraction). */
@@ -146,12 +147,12 @@ typedef struct d3pm_tables_f32 {
   const float* qbar;         /* [T][K][K] q_mats, float32 (dense only)    */
   const float* qoneT;        /* [T][K][K] transpose_q_onestep_mats (dense)*/
   const float* qbarT;        /* [T][K][K] q_mats transposed (dense, for the backward contraction) */
-  /* Optional (both or neither; K = 256): qbar / qbarT as d3pm_table_split_bf16x3 writes them.  When present the
-   * K x K contractions of _at_onehot (:242) run as float32 emulated on the bf16 matrix instructions (three bf16
-   * pieces per operand, six products per term: relative error below 2^-22 per product, against the 2^-24 of a
+  /* Optional (both or neither; K = 256): qbar / qbarT as d3pm_table_split_f16x2 writes them.  When present the
+   * K x K contractions of _at_onehot (:242) run as float32 emulated on the float16 matrix instructions (two float16
+   * pieces per operand, three products per term: relative error below 2^-22 per product, against the 2^-24 of a
    * float32 multiply-add); when NULL, on the float32 matrix instructions. */
-  const uint16_t* qbar_bf16x3;
-  const uint16_t* qbarT_bf16x3;
+  const uint16_t* qbar_f16x2;
+  const uint16_t* qbarT_f16x2;
 } d3pm_tables_f32;
 
 /* Float64 view for the protein-style kernels (structured only). */

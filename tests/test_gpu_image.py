@@ -157,9 +157,9 @@ def test_small_dense_tables_golden(pkg, name, kind, bands):
     check_downstream(d, g)
 
 
-@pytest.mark.parametrize("dense_matmul", ["bf16x3", "f32"])
+@pytest.mark.parametrize("dense_matmul", ["f16x2", "f32"])
 def test_gaussian_k256_golden(pkg, dense_matmul):
-    """The reference's own K = 256 Gaussian run, on both contraction paths: float32 emulated on the bf16 matrix
+    """The reference's own K = 256 Gaussian run, on both contraction paths: float32 emulated on the float16 matrix
     instructions (the default) and the float32 matrix instructions."""
     g = golden("image_gaussian_k256")
     d = make(pkg, g, "gaussian", 8)
@@ -367,13 +367,13 @@ def test_wide_structured_loss_against_oracle(pkg, K, B, npos):
         close(loss_f, loss_ref.detach().numpy(), atol=1e-6, what=f"forward-only loss {kind} K={K}")
 
 
-@pytest.mark.parametrize("dense_matmul", ["bf16x3", "f32"])
+@pytest.mark.parametrize("dense_matmul", ["f16x2", "f32"])
 @pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
 def test_k256_matrix_core_tiles_against_oracle(pkg, B, L, dense_matmul):
     """K = 256 runs its contractions on the matrix cores in tiles of 64 tokens:
     several tiles per workgroup, a partial last tile, a single-token tail, a t = 0
     batch element, more batch elements than one round of the XCD mapping.  Both
-    contraction paths: 'bf16x3' (float32 emulated with three bf16 pieces per operand;
+    contraction paths: 'f16x2' (float32 emulated with two float16 pieces per operand;
     the training loss on the register-tile kernel, everything else on the tile
     kernel) and 'f32' (the float32 matrix instructions)."""
     K, T = 256, 20
@@ -382,7 +382,7 @@ def test_k256_matrix_core_tiles_against_oracle(pkg, B, L, dense_matmul):
                               model_prediction="x_start", model_output="logits", loss_type="hybrid",
                               hybrid_coeff=0.01, device=DEV)
     d.dense_matmul = dense_matmul
-    assert (d.tables().qbar_bf16x3 is not None) == (dense_matmul == "bf16x3")
+    assert (d.tables().qbar_f16x2 is not None) == (dense_matmul == "f16x2")
     p = im.build_process(betas, "gaussian", 8, None, hybrid_coeff=0.01)
     gen = torch.Generator().manual_seed(1000 * B + L)
     x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen)
@@ -627,7 +627,7 @@ def test_raw_ctypes_binding_as_documented(pkg):
         _fields_ = [("K", C.c_int), ("T", C.c_int), ("structured", C.c_int), ("eps", C.c_float),
                     ("qbar_digest", C.c_void_p), ("qone_digest", C.c_void_p),
                     ("qbar", C.c_void_p), ("qoneT", C.c_void_p), ("qbarT", C.c_void_p),
-                    ("qbar_bf16x3", C.c_void_p), ("qbarT_bf16x3", C.c_void_p)]
+                    ("qbar_f16x2", C.c_void_p), ("qbarT_f16x2", C.c_void_p)]
 
     K, T, B, npos = 32, 500, 256, 40
     d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0, 0, T, "jsd"), transition_mat_type="uniform", num_bits=5,
@@ -1220,37 +1220,36 @@ def test_training_step_halves_refuse_two_streams(pkg):
     assert torch.isfinite(out["losses"]).all() and int(counter.item()) == 4
 
 
-def test_table_split_bf16x3_image(pkg):
-    """d3pm_table_split_bf16x3: the three bf16 planes add up to the float32 table exactly, each plane is the
-    round-to-nearest bf16 of what the planes before it left, and the element order is the documented operand image
-    [T, K/32, K/16, 3, 64, 8] (lane kg << 4 | mm of tile mt, slot s = reduction index 32 u + 16 (s >> 2) + 4 kg + (s & 3),
-    output class 16 mt + mm)."""
+def test_table_split_f16x2_image(pkg):
+    """d3pm_table_split_f16x2: the two float16 planes are hi = float16(2^14 x) and lo = float16(2^14 x - hi), round to
+    nearest; together they hold an entry to 2^-22 of its size or 2^-39, whichever is larger; and the element order is
+    the documented operand image [T, K/32, K/16, 2, 64, 8] (lane kg << 4 | mm of tile mt, slot s = reduction index
+    32 u + 16 (s >> 2) + 4 kg + (s & 3), output class 16 mt + mm)."""
     from d3pm_amd._ops import ops
     T, K = 3, 64
     gen = torch.Generator().manual_seed(5)
     tab = (torch.rand(T, K, K, generator=gen) * torch.logspace(-30, 0, K)[None, None, :]).float()
     tab[0, 0, 0] = 0.0
     tab[1, 3, 5] = 1.0
-    img = ops.table_split_bf16x3(tab.to(DEV)).cpu()
-    assert img.shape == (T, K // 32, K // 16, 3, 64, 8) and img.dtype == torch.bfloat16
+    img = ops.table_split_f16x2(tab.to(DEV)).cpu()
+    assert img.shape == (T, K // 32, K // 16, 2, 64, 8) and img.dtype == torch.float16
     u, mt, lane, sl = torch.meshgrid(torch.arange(K // 32), torch.arange(K // 16), torch.arange(64), torch.arange(8),
                                      indexing="ij")
     k = 32 * u + 16 * (sl >> 2) + 4 * (lane >> 4) + (sl & 3)
     m = 16 * mt + (lane & 15)
-    want = tab[:, k, m]                                        # [T, K/32, K/16, 64, 8]
-    hi = want.bfloat16()
-    r1 = want - hi.float()
-    mid = r1.bfloat16()
-    lo = (r1 - mid.float()).bfloat16()
-    assert torch.equal(img[:, :, :, 0], hi) and torch.equal(img[:, :, :, 1], mid) and torch.equal(img[:, :, :, 2], lo)
-    total = img[:, :, :, 0].double() + img[:, :, :, 1].double() + img[:, :, :, 2].double()
-    assert torch.equal(total.float(), want)                    # 3 x 8 significant bits hold a float32 exactly
+    want = tab[:, k, m] * 16384.0                              # [T, K/32, K/16, 64, 8]; exact: a power of two
+    hi = want.half()
+    lo = (want - hi.float()).half()
+    assert torch.equal(img[:, :, :, 0], hi) and torch.equal(img[:, :, :, 1], lo)
+    total = (img[:, :, :, 0].double() + img[:, :, :, 1].double()) / 16384.0
+    err = (total - tab[:, k, m].double()).abs()
+    assert bool((err <= torch.maximum(tab[:, k, m].double() * 2.0 ** -22, torch.tensor(2.0 ** -39, dtype=torch.float64))).all())
     with pytest.raises(ValueError):
-        ops.table_split_bf16x3(torch.zeros(2, 24, 24, device=DEV))
+        ops.table_split_f16x2(torch.zeros(2, 24, 24, device=DEV))
 
 
 def test_split_tables_shape_contract(pkg):
-    """The operators refuse bf16 split tables of the wrong size, a lone one, or ones attached to another alphabet."""
+    """The operators refuse float16 split tables of the wrong size, a lone one, or ones attached to another alphabet."""
     from d3pm_amd._ops import ops
     d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(1e-3, 0.3, 6, "linear"), transition_mat_type="gaussian", num_bits=8,
                               transition_bands=None, model_prediction="x_start", model_output="logits",
@@ -1260,7 +1259,7 @@ def test_split_tables_shape_contract(pkg):
     x0 = torch.zeros(2, 5, dtype=torch.int64, device=DEV)
     t = torch.ones(2, dtype=torch.int32, device=DEV)
     ops.q_probs(tabs, K, T, structured, eps, x0, t)
-    empty = torch.empty(0, dtype=torch.bfloat16, device=DEV)
+    empty = torch.empty(0, dtype=torch.float16, device=DEV)
     for bad in (tabs[:5] + [tabs[5][:-1], tabs[6]], tabs[:5] + [tabs[5], empty], tabs[:6]):
         with pytest.raises((ValueError, RuntimeError)):
             ops.q_probs(bad, K, T, structured, eps, x0, t)
