@@ -925,8 +925,7 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       int rc;
       if constexpr (SP) {
         // 256 classes with the split tables: the training form (gradient asked for) on the register-tile kernel
-        // (251-261 us against the tile kernel's 272 at B = 128 x 1024 tokens; forward only the tile kernel is
-        // the faster one, 124 against 128-135)
+        // (202 us at B = 128 x 1024 tokens; forward only the tile kernel is the faster one, 95 against 108)
         rc = dlogits ? launch_loss256(a, e, B, s)
                      : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
       } else {

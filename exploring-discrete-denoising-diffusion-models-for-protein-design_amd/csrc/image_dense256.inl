@@ -31,8 +31,12 @@ namespace d3pm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RT_STAGE = 8 * 2 * 1024;        // bytes of one ring stage
-constexpr int RT_RING = 4;                     // stages in the LDS ring
+constexpr int RT_BS = 8;               // blocks (class tiles of one reduction block) per ring stage
+constexpr int RT_STAGE = RT_BS * 2 * 1024;    // bytes of one ring stage
+constexpr int RT_NS = 128 / RT_BS;            // stages per contraction
+constexpr int RT_DMA = RT_STAGE / 4096;       // DMA instructions per wave and stage
+constexpr int RT_RING = 4;                      // stages in the LDS ring (3 x 24 KB, 6 or 8 x 8 KB, 16 x 4 KB: equal)
+constexpr int RT_LA = RT_RING - 1;            // a stage's DMA is issued this many stages ahead
 constexpr int RT_TABLE = 2 * 256 * 256 * 2;   // bytes of one timestep's operand image
 constexpr float RT_SCALE = 16384.0f;          // 2^14: what the table image and the forward activations are scaled by
 
@@ -59,7 +63,7 @@ __device__ __forceinline__ void ring_dma(const __amdgpu_buffer_rsrc_t& trs, char
   int off;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(off));
 #pragma unroll
-  for (int i = 0; i < RT_STAGE / 4096; ++i)
+  for (int i = 0; i < RT_DMA; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % RT_RING) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
                                              s * RT_STAGE + i * 4096 + wave * 1024, 0, 0);
 }
@@ -71,9 +75,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const char* table) 
 // waves do until the contraction.
 __device__ __forceinline__ void ring_begin(const char* table, char* ring) {
   const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
-  ring_dma(trs, ring, 0);
-  ring_dma(trs, ring, 1);
-  ring_dma(trs, ring, 2);
+#pragma unroll
+  for (int s = 0; s < RT_LA; ++s) ring_dma(trs, ring, s);
 }
 // Barrier of the ring: waits until all but the wave's `pending` most recent DMA instructions have landed (and its
 // LDS reads have returned), then meets the other waves.  Not __syncthreads(): its fence waits for every DMA.
@@ -102,7 +105,7 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   };
   struct Frag { u32x4 hi, lo; };
   auto read_frag = [&](int j) {       // block j = 8 s + ml
-    const char* st = ring + ((j >> 3) % RT_RING) * RT_STAGE + (j & 7) * 2048 + lane * 16;
+    const char* st = ring + ((j / RT_BS) % RT_RING) * RT_STAGE + (j % RT_BS) * 2048 + lane * 16;
     Frag f;
     f.hi = *reinterpret_cast<const u32x4*>(st);
     f.lo = *reinterpret_cast<const u32x4*>(st + 1024);
@@ -117,9 +120,11 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int mt = 0; mt < 16; ++mt) out[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  ring_barrier<RT_STAGE / 4096>();       // stages 0 and 1 have landed and are visible; stage 2 may be on its way
+  ring_barrier<(RT_LA - 2) * RT_DMA>();       // stages 0 and 1 have landed and are visible; later ones may be on their way
   __builtin_amdgcn_s_setprio(0);     // the co-resident workgroup's per-token arithmetic issues ahead of this stream
-  Frag fr[3];
+  // blocks go in pairs (two class tiles: two independent accumulators, their matrix instructions interleaved);
+  // the piece reads run one pair ahead
+  Frag fr[4];
   fr[0] = read_frag(0);
   fr[1] = read_frag(1);
   // the activations' pieces of reduction block u + 1 are formed in the middle of block u's second stage, pinned
@@ -134,29 +139,46 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   for (int u = 0; u < 8; ++u) {
     const Pieces& b = pc[u & 1];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int s = 2 * u + half;
-      if (s + 3 < 16) ring_dma(trs, ring, s + 3);
+    for (int q = 0; q < 16 / RT_BS; ++q) {
+      const int s = u * (16 / RT_BS) + q;
+      if (s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
 #pragma unroll
-      for (int ml = 0; ml < 8; ++ml) {
-        const int j = 8 * s + ml;
-        if (j + 2 < 128) fr[(j + 2) % 3] = read_frag(j + 2);
+      for (int ml = 0; ml < RT_BS; ml += 2) {
+        const int j = RT_BS * s + ml, mt = j & 15;
+        if (j + 2 < 128) {
+          fr[(j + 2) % 4] = read_frag(j + 2);
+          fr[(j + 3) % 4] = read_frag(j + 3);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        const Frag& f = fr[j % 3];
-        f32x4& d = out[8 * half + ml];
-        mm(d, f.lo, b.hi);      // small terms first
-        mm(d, f.hi, b.lo);
-        mm(d, f.hi, b.hi);
+        const Frag &f0 = fr[j % 4], &f1 = fr[(j + 1) % 4];
+        f32x4 &d0 = out[mt], &d1 = out[mt + 1];
+        mm(d0, f0.lo, b.hi);      // small terms first
+        mm(d1, f1.lo, b.hi);
+        mm(d0, f0.hi, b.lo);
+        mm(d1, f1.hi, b.lo);
+        mm(d0, f0.hi, b.hi);
+        mm(d1, f1.hi, b.hi);
         __builtin_amdgcn_sched_barrier(0);
-        if (half == 1 && ml == 3 && u + 1 < 8) {
+        if (mt == 10 && u + 1 < 8) {
           Pieces& nx = pc[(u + 1) & 1];
           split_f16x2(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.lo);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // stage s + 2 has landed (the piece reads reach it before the next barrier); stage s + 3 may be in flight
-      if (s + 3 < 16) ring_barrier<RT_STAGE / 4096>();
-      else ring_barrier<0>();
+      // stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be in flight
+      {
+        const int last = s + RT_LA < RT_NS ? s + RT_LA : RT_NS - 1;      // latest stage requested so far
+        const int pend = last - (s + 2) > 0 ? last - (s + 2) : 0;
+        switch (pend) {                                                  // (compile-time after unrolling)
+          case 0: ring_barrier<0>(); break;
+          case 1: ring_barrier<1 * RT_DMA>(); break;
+          case 2: ring_barrier<2 * RT_DMA>(); break;
+          case 3: ring_barrier<3 * RT_DMA>(); break;
+          case 4: ring_barrier<4 * RT_DMA>(); break;
+          case 5: ring_barrier<5 * RT_DMA>(); break;
+          default: ring_barrier<6 * RT_DMA>(); break;
+        }
+      }
     }
   }
   __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
