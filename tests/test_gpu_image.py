@@ -174,8 +174,9 @@ def test_gaussian_k256_golden(pkg, dense_matmul):
 
 
 def test_seeded_against_oracle_odd_shapes(pkg):
-    """K not a multiple of 4, int32 tokens, 2-D data, B=1 and npos=1."""
-    for bits, B, shape in ((3, 5, (7,)), (3, 1, (1,)), (6, 3, (5, 2)), (7, 2, (3, 3, 1))):
+    """K not a multiple of 4, int32 tokens, 2-D data, B=1 and npos=1; K = 4 is the alphabet no specialised loss kernel
+    takes (the lane-group kernel k_hybrid_loss)."""
+    for bits, B, shape in ((3, 5, (7,)), (3, 1, (1,)), (6, 3, (5, 2)), (7, 2, (3, 3, 1)), (2, 4, (9,)), (2, 200, (33,))):
         K = 2 ** bits
         betas = pkg.generate_betas(0.02, 0.5, 12, "linear")
         for kind in ("uniform", "absorbing", "gaussian"):
