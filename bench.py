@@ -350,7 +350,7 @@ def worker(args):
 
     # ---- duration of the dominant kernel: the same launch (same buffers) back to back on the stream, HIP events
     # at both ends; rocprofv3 --kernel-trace of this command reports the same kernel's average duration (profiles/).
-    def fused_kernel_ms(dd, nsets=1, with_next=False, replayed=False):
+    def fused_kernel_ms(dd, nsets=1, with_next=False, replayed=False, copy=False):
         """nsets > 1 rotates through that many disjoint sets of inputs and outputs (> 256 MiB in all), so that no
         launch finds its rows in the Infinity Cache: that figure is HBM traffic proper."""
         tb = dd.tables()
@@ -371,6 +371,16 @@ def worker(args):
             check(lib.d3pm_hybrid_loss(tb.desc(), ptr(lg_i), K, ptr(x0_i), 8, ptr(xt_i), 8, ptr(t_s), 4, B, L,
                                        LOSS["hybrid"], LAMBDA, 1.0 / B, None, None, None, ptr(loss_s), ptr(dl_i), None,
                                        None, 0, ptr(ws), wsb, sp if spx is None else spx))
+        if copy:
+            # a plain device copy over the same buffers (torch's elementwise copy kernel, dlogits <- logits: 8K of the
+            # launch's 8K + 16 bytes per token, no arithmetic): what the memory system gives a streaming kernel of
+            # this size and access pattern
+            def copy_only():
+                _, _, lg_i, dl_i = sets[state["i"] % nsets]
+                state["i"] += 1
+                dl_i.copy_(lg_i)
+            blocks = sorted(event_ms(copy_only, max(args.steps, 200), warm=2 * nsets + 10) for _ in range(5))
+            return blocks[2]
         if replayed:
             return event_ms_replayed(fused_only, max(args.steps, 200), per_graph=10 * nsets if nsets > 1 else 50)
         if not with_next:
@@ -584,6 +594,8 @@ def worker(args):
     progress("fused kernel back to back")
     kern_ms = fused_kernel_ms(d)
     kern_rot_ms = fused_kernel_ms(d, nsets=10)
+    copy_rot_ms = fused_kernel_ms(d, nsets=10, copy=True)
+    copy_ms = fused_kernel_ms(d, copy=True)
     kern_next_ms = fused_kernel_ms(d, with_next=True) if pipelined else None
     kern_replayed_ms = fused_kernel_ms(d, replayed=True) if not args.no_graph and not use_pg else None
 
@@ -866,6 +878,13 @@ def worker(args):
                         "*_cache_resident: one 35.7 MB working set relaunched back to back, which stays in the "
                         "256 MiB Infinity Cache; `bench.py --roofline-only` launches exactly the rotating sequence "
                         "(the program of the committed rocprofv3 kernel trace)"}
+        roof["plain_copy_same_buffers"] = {
+            "what": "torch copy_ of the logits tensor into the gradient tensor over the same buffer sets (8K of the kernel's "
+                    "8K + 16 bytes per token, no arithmetic), timed the same way",
+            "ms_rotating": copy_rot_ms, "ms_cache_resident": copy_ms,
+            "GBps_rotating": 8 * K * B * L / (copy_rot_ms * 1e-3) / 1e9,
+            "GBps_cache_resident": 8 * K * B * L / (copy_ms * 1e-3) / 1e9,
+            "kernel_over_copy_rotating": kern_rot_ms / copy_rot_ms}
         traced = traced_duration_ms(HEAD_KERNEL)
         if traced:
             # the tracer serialises the dispatches and brackets each with its own packets: a kernel of this size

@@ -57,5 +57,17 @@ int main() {
   time("flat_2048x256", [&] { k_flat<<<2048, 256>>>((const float4*)in, x0, xt, (float4*)out, N * K / 4); });
   time("flat_1024x256", [&] { k_flat<<<1024, 256>>>((const float4*)in, x0, xt, (float4*)out, N * K / 4); });
   time("empty", [&] { k_empty<<<256, 1024>>>(out); });
+  // the same copies over ten disjoint sets of buffers in rotation (357 MB: more than the 256 MiB Infinity Cache holds,
+  // every launch reads its rows from HBM proper) -- the floor of the figure the benchmark's roofline.frac is quoted on
+  constexpr int SETS = 10;
+  float *ins[SETS], *outs[SETS]; int64_t *x0s[SETS], *xts[SETS];
+  for (int i = 0; i < SETS; ++i) {
+    hipMalloc(&ins[i], N * K * 4); hipMalloc(&outs[i], N * K * 4); hipMalloc(&x0s[i], N * 8); hipMalloc(&xts[i], N * 8);
+    hipMemset(ins[i], 0, N * K * 4); hipMemset(x0s[i], 0, N * 8); hipMemset(xts[i], 0, N * 8);
+  }
+  int r = 0;
+  time("rows_per_sample/rot", [&] { k_rows_per_sample<<<B, 1024>>>(ins[r], x0s[r], xts[r], outs[r]); r = (r + 1) % SETS; });
+  time("flat_2048x256/rot", [&] { k_flat<<<2048, 256>>>((const float4*)ins[r], x0s[r], xts[r], (float4*)outs[r], N * K / 4); r = (r + 1) % SETS; });
+  time("flat_1024x256/rot", [&] { k_flat<<<1024, 256>>>((const float4*)ins[r], x0s[r], xts[r], (float4*)outs[r], N * K / 4); r = (r + 1) % SETS; });
   return 0;
 }
