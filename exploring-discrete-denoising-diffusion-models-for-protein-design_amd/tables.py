@@ -65,7 +65,9 @@ class ImageTables:
             self.qbar = ops.table_to_f32(q_mats)
             self.qbarT = ops.table_to_f32(q_mats.permute(0, 2, 1))
             self.qoneT = ops.table_to_f32(q_onestep.permute(0, 2, 1))
-            if K == 256 and dense_matmul == "f16x2":
+            # the float16 pieces carry 2^14 x the entry: tables of probabilities only (a caller's own q_mats with
+            # entries above 1 -- not a transition table -- stay on the float32 instructions; one host read at set-up)
+            if K == 256 and dense_matmul == "f16x2" and float(self.qbar.abs().max()) <= 1.0 + 1e-6:
                 self.qbar_f16x2 = ops.table_split_f16x2(self.qbar)
                 self.qbarT_f16x2 = ops.table_split_f16x2(self.qbarT)
         self.dense_matmul = dense_matmul if self.qbar_f16x2 is not None else "f32"

@@ -1249,6 +1249,20 @@ def test_table_split_f16x2_image(pkg):
         ops.table_split_f16x2(torch.zeros(2, 24, 24, device=DEV))
 
 
+def test_split_tables_only_for_probabilities(pkg):
+    """Tables with entries above 1 (not transition probabilities) stay on the float32 matrix instructions: the float16
+    pieces carry 2^14 x the entry."""
+    from d3pm_amd.tables import ImageTables
+    T, K = 2, 256
+    gen = torch.Generator().manual_seed(3)
+    q = torch.rand(T, K, K, generator=gen, dtype=torch.float64)
+    q = q / q.sum(-1, keepdim=True)
+    assert ImageTables(q.to(DEV), q.to(DEV)).dense_matmul == "f16x2"
+    big = q.clone()
+    big[1, 7, 9] = 3.0
+    assert ImageTables(big.to(DEV), q.to(DEV)).dense_matmul == "f32"
+
+
 def test_split_tables_shape_contract(pkg):
     """The operators refuse float16 split tables of the wrong size, a lone one, or ones attached to another alphabet."""
     from d3pm_amd._ops import ops
