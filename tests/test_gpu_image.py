@@ -904,6 +904,30 @@ def test_training_step_timestep_distribution_and_graph(pkg):
     np.testing.assert_allclose(float(dm["loss"]), float(dm["losses"].double().mean()), rtol=1e-5)
 
 
+def test_training_step_graph_dense_k256(pkg):
+    """The captured training step on dense tables with 256 classes (the register-tile loss kernel with its LDS-DMA
+    table stream, the dense forward corruption): every replay draws anew, and its losses and gradient equal the eager
+    fused loss on the replay's own x_t and t."""
+    K, T, B, L = 256, 30, 10, 200
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(1e-3, 0.2, T, "linear"), transition_mat_type="gaussian", num_bits=8,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    assert d.tables().dense_matmul == "f16x2"
+    x0 = torch.randint(0, K, (B, L, 1, 1), device=DEV)
+    logits = torch.randn(B, L, 1, 1, K, device=DEV, requires_grad=True)
+    g = pkg.graphs.GraphedTrainingStep(d, lambda x, tt: logits, x0, seed=5, params=[logits])
+    seen = []
+    for _ in range(3):
+        out = g.replay()
+        seen.append(out["x_t"].clone())
+        lg = logits.detach().clone().requires_grad_(True)
+        ref = d._fused(lg, x0, out["x_t"], out["t"], "hybrid")
+        ref.mean().backward()
+        assert torch.equal(out["losses"], ref.detach())
+        assert torch.equal(logits.grad, lg.grad)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
 def test_training_step_several_steps_per_graph(pkg):
     """Three consecutive steps captured in one graph over a ring of three batches
     equal three eager steps on the same Philox counter values."""
