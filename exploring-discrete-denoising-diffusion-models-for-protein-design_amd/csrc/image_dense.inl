@@ -910,6 +910,32 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
   D3PM_CHECK_ARG(!dlogits || tb->qbarT, "dense backward needs the transposed cumulative table (qbarT)");
   const bool vec = aligned16(logits) && ld == tb->K && (!dlogits || aligned16(dlogits)) && aligned16(tb->qbar) &&
                    aligned16(tb->qoneT);
+  // 64, 128 or 256 classes with the float16 split tables: the register-tile kernel (k_dense_loss256) -- at 256
+  // classes for the training form only (forward only the tile kernel below is the faster one, 95 against 108 us at
+  // B = 128 x 1024 tokens); at 64 and 128 classes, where the tile kernel contracts on the vector ALUs, for both
+  const int K = tb->K;
+  if (vec && tb->qbar_f16x2 && tb->qbarT_f16x2 && (K == 64 || K == 128 || (K == 256 && dlogits))) {
+    ImgArgs a = make_args(tb, x0, tok_bytes, x_t, xt_bytes, t, t_bytes, B, npos, 1);
+    const TokenGrid tg = token_grid(B, npos, 64, 1024);      // tiles of 64 tokens, two workgroups per CU, two rounds
+    a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
+    const size_t need = (size_t)B * a.chunks * 2 * sizeof(float);
+    D3PM_CHECK_WORKSPACE(workspace, workspace_bytes, need);
+    DenseExtra e{};
+    e.logits = logits; e.ld = ld; e.loss_type = loss_type; e.hybrid_coeff = hybrid_coeff; e.grad_scale = grad_scale;
+    e.grad_out = grad_out; e.part = (float*)workspace; e.dlogits = dlogits;
+    e.rng_counter = o.rng_counter; e.rng_step = o.rng_step;
+    int rc;
+    if (K == 256) rc = launch_loss256<256, true>(a, e, B, s);
+    else if (K == 128) rc = dlogits ? launch_loss256<128, true>(a, e, B, s) : launch_loss256<128, false>(a, e, B, s);
+    else rc = dlogits ? launch_loss256<64, true>(a, e, B, s) : launch_loss256<64, false>(a, e, B, s);
+    if (rc) return rc;
+    LossOut oo = o;
+    oo.part = e.part;
+    hipLaunchKernelGGL(k_loss_finalize, dim3((B + 255) / 256), dim3(256), 0, s, oo, B, a.chunks, npos, loss_type,
+                       hybrid_coeff, 1.0f / LN2);
+    D3PM_LAUNCH_CHECK("k_loss_finalize");
+    return D3PM_OK;
+  }
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);
     return with_mfma_choice<decltype(lay)>(tb, [&](auto lay2, auto mf) {
@@ -924,10 +950,8 @@ static int dense_hybrid_loss(const d3pm_tables_f32* tb, const float* logits, lon
       e.rng_counter = o.rng_counter; e.rng_step = o.rng_step;
       int rc;
       if constexpr (SP) {
-        // 256 classes with the split tables: the training form (gradient asked for) on the register-tile kernel
-        // (202 us at B = 128 x 1024 tokens; forward only the tile kernel is the faster one, 95 against 108)
-        rc = dlogits ? launch_loss256(a, e, B, s)
-                     : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
+        // (the training form took the register-tile kernel above)
+        rc = launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);
       } else {
         rc = dlogits ? launch_tile<L, DENSE_LOSS, true, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s)
                      : launch_tile<L, DENSE_LOSS, false, D3PM_NOISE_GUMBEL, MF, SP>(tb, a, e, B, s);

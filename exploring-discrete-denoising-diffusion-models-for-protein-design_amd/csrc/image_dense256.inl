@@ -33,12 +33,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RT_BS = 8;               // blocks (class tiles of one reduction block) per ring stage
 constexpr int RT_STAGE = RT_BS * 2 * 1024;    // bytes of one ring stage
-constexpr int RT_NS = 128 / RT_BS;            // stages per contraction
 constexpr int RT_DMA = RT_STAGE / 4096;       // DMA instructions per wave and stage
 constexpr int RT_RING = 4;                      // stages in the LDS ring (3 x 24 KB, 6 or 8 x 8 KB, 16 x 4 KB: equal)
 constexpr int RT_LA = RT_RING - 1;            // a stage's DMA is issued this many stages ahead
-constexpr int RT_TABLE = 2 * 256 * 256 * 2;   // bytes of one timestep's operand image
 constexpr float RT_SCALE = 16384.0f;          // 2^14: what the table image and the forward activations are scaled by
+// K classes: K / 16 class tiles (elements (mt, .) of a lane's arrays), K / 32 reduction blocks, K^2 / 512 blocks of
+// (reduction block, class tile) = K^2 / 4096 ring stages per contraction (256 classes: 16, 128: 4, 64: 1)
+template <int K>
+struct RtCfg {
+  static_assert(K == 64 || K == 128 || K == 256, "alphabets of 64, 128 or 256 classes");
+  static constexpr int NMT = K / 16, NU = K / 32, NBLK = NU * NMT, NS = NBLK / RT_BS;
+  static constexpr int TABLE = 2 * K * K * 2;                     // bytes of one timestep's operand image
+  static constexpr int SPLIT_AT = NMT >= 8 ? NMT - 6 : NMT - 2;   // class tile (pair) after which the next block's pieces are formed
+};
 
 __device__ __forceinline__ float quad_lanes_sum(float x) {      // over lanes tok, tok+16, tok+32, tok+48
   x += __shfl_xor(x, 16);
@@ -67,16 +74,18 @@ __device__ __forceinline__ void ring_dma(const __amdgpu_buffer_rsrc_t& trs, char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % RT_RING) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
                                              s * RT_STAGE + i * 4096 + wave * 1024, 0, 0);
 }
+template <int K>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const char* table) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, RT_TABLE, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, RtCfg<K>::TABLE, 0x00020000);
 }
 // Requests the first three stages of `table`.  Call once every wave of the workgroup is past its last read of the
 // ring (regtile_contract ends with a barrier), as early as the table is known: the stages arrive under whatever the
 // waves do until the contraction.
+template <int K>
 __device__ __forceinline__ void ring_begin(const char* table, char* ring) {
-  const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
+  const __amdgpu_buffer_rsrc_t trs = table_rsrc<K>(table);
 #pragma unroll
-  for (int s = 0; s < RT_LA; ++s) ring_dma(trs, ring, s);
+  for (int s = 0; s < RT_LA && s < RtCfg<K>::NS; ++s) ring_dma(trs, ring, s);
 }
 // Barrier of the ring: waits until all but the wave's `pending` most recent DMA instructions have landed (and its
 // LDS reads have returned), then meets the other waves.  Not __syncthreads(): its fence waits for every DMA.
@@ -96,10 +105,13 @@ __device__ __forceinline__ void ring_barrier() {
 // stage's DMA instructions: two stages of cover) and is read from the end of stage s - 1 on: the piece reads run two
 // blocks ahead of the matrix instructions and cross the stage boundaries, so neither a barrier nor an LDS latency
 // sits between two stages' matrix instructions.
-__device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring, const f32x4 (&act)[16],
-                                                 f32x4 (&out)[16]) {
+template <int K>
+__device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring,
+                                                 const f32x4 (&act)[K / 16], f32x4 (&out)[K / 16]) {
+  using C = RtCfg<K>;
+  constexpr int NMT = C::NMT, NU = C::NU, NBLK = C::NBLK, RT_NS = C::NS;
   const int lane = threadIdx.x & 63;
-  const __amdgpu_buffer_rsrc_t trs = table_rsrc(table);
+  const __amdgpu_buffer_rsrc_t trs = table_rsrc<K>(table);
   auto mm = [&](f32x4& d, const u32x4& x, const u32x4& y) {
     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), d, 0, 0, 0);
   };
@@ -116,11 +128,12 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   // takes every element as an in-out operand (no instruction is emitted) pins them, the scheduling fence keeps
   // the machine scheduler from moving anything across
 #pragma unroll
-  for (int mt = 0; mt < 16; ++mt) asm volatile("" : "+v"(const_cast<f32x4&>(act[mt])));
+  for (int mt = 0; mt < NMT; ++mt) asm volatile("" : "+v"(const_cast<f32x4&>(act[mt])));
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int mt = 0; mt < 16; ++mt) out[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  ring_barrier<(RT_LA - 2) * RT_DMA>();       // stages 0 and 1 have landed and are visible; later ones may be on their way
+  for (int mt = 0; mt < NMT; ++mt) out[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // stages 0 and 1 have landed and are visible; later ones may be on their way
+  ring_barrier<((RT_LA < RT_NS ? RT_LA : RT_NS) > 2 ? (RT_LA < RT_NS ? RT_LA : RT_NS) - 2 : 0) * RT_DMA>();
   __builtin_amdgcn_s_setprio(0);     // the co-resident workgroup's per-token arithmetic issues ahead of this stream
   // blocks go in pairs (two class tiles: two independent accumulators, their matrix instructions interleaved);
   // the piece reads run one pair ahead
@@ -136,47 +149,41 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   split_f16x2(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].lo);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const Pieces& b = pc[u & 1];
 #pragma unroll
-    for (int q = 0; q < 16 / RT_BS; ++q) {
-      const int s = u * (16 / RT_BS) + q;
-      if (s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
-#pragma unroll
-      for (int ml = 0; ml < RT_BS; ml += 2) {
-        const int j = RT_BS * s + ml, mt = j & 15;
-        if (j + 2 < 128) {
-          fr[(j + 2) % 4] = read_frag(j + 2);
-          fr[(j + 3) % 4] = read_frag(j + 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const Frag &f0 = fr[j % 4], &f1 = fr[(j + 1) % 4];
-        f32x4 &d0 = out[mt], &d1 = out[mt + 1];
-        mm(d0, f0.lo, b.hi);      // small terms first
-        mm(d1, f1.lo, b.hi);
-        mm(d0, f0.hi, b.lo);
-        mm(d1, f1.hi, b.lo);
-        mm(d0, f0.hi, b.hi);
-        mm(d1, f1.hi, b.hi);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mt == 10 && u + 1 < 8) {
-          Pieces& nx = pc[(u + 1) & 1];
-          split_f16x2(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.lo);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int mt = 0; mt < NMT; mt += 2) {
+      const int j = u * NMT + mt, s = j / RT_BS;              // block (u, mt) is block j of the image; its stage
+      if (j % RT_BS == 0 && s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
+      if (j + 2 < NBLK) {
+        fr[(j + 2) % 4] = read_frag(j + 2);
+        fr[(j + 3) % 4] = read_frag(j + 3);
       }
-      // stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be in flight
-      {
+      __builtin_amdgcn_sched_barrier(0);
+      const Frag &f0 = fr[j % 4], &f1 = fr[(j + 1) % 4];
+      f32x4 &d0 = out[mt], &d1 = out[mt + 1];
+      mm(d0, f0.lo, b.hi);      // small terms first
+      mm(d1, f1.lo, b.hi);
+      mm(d0, f0.hi, b.lo);
+      mm(d1, f1.hi, b.lo);
+      mm(d0, f0.hi, b.hi);
+      mm(d1, f1.hi, b.hi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mt == C::SPLIT_AT && u + 1 < NU) {
+        Pieces& nx = pc[(u + 1) & 1];
+        split_f16x2(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.lo);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // end of a stage: stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be
+      // in flight
+      if (j % RT_BS == RT_BS - 2) {
         const int last = s + RT_LA < RT_NS ? s + RT_LA : RT_NS - 1;      // latest stage requested so far
         const int pend = last - (s + 2) > 0 ? last - (s + 2) : 0;
         switch (pend) {                                                  // (compile-time after unrolling)
           case 0: ring_barrier<0>(); break;
           case 1: ring_barrier<1 * RT_DMA>(); break;
           case 2: ring_barrier<2 * RT_DMA>(); break;
-          case 3: ring_barrier<3 * RT_DMA>(); break;
-          case 4: ring_barrier<4 * RT_DMA>(); break;
-          case 5: ring_barrier<5 * RT_DMA>(); break;
-          default: ring_barrier<6 * RT_DMA>(); break;
+          default: ring_barrier<3 * RT_DMA>(); break;
         }
       }
     }
@@ -185,11 +192,12 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool GRAD>
+template <int K, bool GRAD>
 __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra e) {
   extern __shared__ __align__(16) char ring[];
   __shared__ float red[2 * 4];
-  constexpr int K = 256;
+  constexpr int NMT = K / 16;                   // class tiles = 16-byte pieces of a lane's share of a row
+  constexpr int RT_TABLE = RtCfg<K>::TABLE;
   const float eps = a.tb.eps;
   if (blockIdx.x == 0 && threadIdx.x == 0 && e.rng_counter) *e.rng_counter += e.rng_step;
   // workgroup -> (batch element, chunk) as in k_dense_tile: all chunks of an element on one XCD
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
 #define D3PM_PHASE256(i) do {} while (0)
 #endif
   __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
-  if (need_post) ring_begin(tableF, ring);
+  if (need_post) ring_begin<K>(tableF, ring);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += 64) {
     const long pos = tile0 + 16 * wave + tok;
     const bool live = pos < p1;
@@ -235,19 +243,19 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64 * mt, 0, 0));
     };
     // ---- softmax of the token's logits, cross-entropy term
-    f32x4 v[16];
+    f32x4 v[NMT];
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt) v[mt] = load_row4(zrs, rowoff, mt);
+    for (int mt = 0; mt < NMT; ++mt) v[mt] = load_row4(zrs, rowoff, mt);
     const float zx0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, rowoff - 16 * kg + 4 * x0, 0, 0));
     float m = v[0][0];
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, v[mt][r]);
     m = quad_lanes_max(m);
     float sum = 0;
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[mt][r] = fast_exp2((v[mt][r] - m) * LOG2E); sum += v[mt][r]; }
     sum = quad_lanes_sum(sum);
@@ -255,15 +263,15 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
     const float ce = fmaf(fast_log2(sum), LN2, m) - zx0;
     const float pscale = live ? inv * RT_SCALE : 0.0f;      // the contraction's operand: pi x 2^14 (float16 pieces)
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt) v[mt] *= pscale;
+    for (int mt = 0; mt < NMT; ++mt) v[mt] *= pscale;
     float vb = ce;
     D3PM_PHASE256(1);
     if (need_post) {
       // ---- f2 = pi @ Qbar_{t-1}
-      f32x4 f2[16];
-      regtile_contract(tableF, ring, v, f2);
-      if (GRAD) ring_begin(tableB, ring);
-      else if (tile0 + 64 < p1) ring_begin(tableF, ring);
+      f32x4 f2[NMT];
+      regtile_contract<K>(tableF, ring, v, f2);
+      if (GRAD) ring_begin<K>(tableB, ring);
+      else if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
       D3PM_PHASE256(2);
       // ---- KL(q || p) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of Qbar_{t-1} + eps,
       // f2 += eps), one log per class; d loss / d f2 replaces f2 in its registers
@@ -272,15 +280,15 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(a.tb.qbar) + (size_t)(t - 1) * K * K, 0, K * K * 4, 0x00020000);
       const int aoff = xt * (K * 4) + 16 * kg, boff = x0 * (K * 4) + 16 * kg;
-      f32x4 av[16], bv[16];
+      f32x4 av[NMT], bv[NMT];
 #pragma unroll
-      for (int mt = 0; mt < 16; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         av[mt] = load_row4(ars, aoff, mt) + eps;
         bv[mt] = load_row4(brs, boff, mt) + eps;
       }
       float zm = 0, zt = 0;
 #pragma unroll
-      for (int mt = 0; mt < 16; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f2[mt][r] = fmaf(f2[mt][r], 1.0f / (RT_SCALE * RT_SCALE), eps);
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       const float wv = live ? w_vb : 0.0f;
       float kl = 0;
 #pragma unroll
-      for (int mt = 0; mt < 16; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float br = bv[mt][r] * fast_rcp(f2[mt][r]);
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
         // significant bits of the largest elements and an absolute 2^-39 of that scale below
         float mx = 0;
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(f2[mt][r]));
         mx = quad_lanes_max(mx);
@@ -316,19 +324,19 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
         const float sc = __builtin_ldexpf(1.0f, 14 - ex);
         unscale = __builtin_ldexpf(1.0f, ex - 28);                                // 1 / (sc x 2^14)
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) f2[mt] *= sc;
+        for (int mt = 0; mt < NMT; ++mt) f2[mt] *= sc;
       }
       if constexpr (GRAD) {
         // ---- d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T, then through the softmax (re-formed from the
         // re-read row with the same max and 1 / sum: bit-identical) plus the cross-entropy term
-        f32x4 gp[16];
-        regtile_contract(tableB, ring, f2, gp);
-        if (tile0 + 64 < p1) ring_begin(tableF, ring);
+        f32x4 gp[NMT];
+        regtile_contract<K>(tableB, ring, f2, gp);
+        if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
         D3PM_PHASE256(4);
-        f32x4 pi[16];
+        f32x4 pi[NMT];
         float dot = 0;
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) {
+        for (int mt = 0; mt < NMT; ++mt) {
           const f32x4 z = load_row4(zrs, rowoff, mt);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
           const __amdgpu_buffer_rsrc_t grs =
               __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
 #pragma unroll
-          for (int mt = 0; mt < 16; ++mt) {
+          for (int mt = 0; mt < NMT; ++mt) {
             const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
             f32x4 gz;
 #pragma unroll
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
         const __amdgpu_buffer_rsrc_t grs =
             __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) {
+        for (int mt = 0; mt < NMT; ++mt) {
           const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
           f32x4 gz;
 #pragma unroll
@@ -400,9 +408,10 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
   }
 }
 
+template <int K, bool GRAD>
 static int launch_loss256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
-  auto kern = k_dense_loss256<true>;
-  const int sh = RT_RING * RT_STAGE;
+  auto kern = k_dense_loss256<K, GRAD>;
+  const int sh = (RtCfg<K>::NS < RT_RING ? RtCfg<K>::NS : RT_RING) * RT_STAGE;
   hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   DenseExtra ee = e;

@@ -86,7 +86,8 @@ void need_image_tables(at::TensorList tables, int64_t K, int64_t T, bool structu
     const bool h0 = tables[5].defined() && tables[5].numel() > 0, h1 = tables[6].defined() && tables[6].numel() > 0;
     TORCH_CHECK_VALUE(h0 == h1, "d3pm_mi355x: the float16 split tables come as a pair (qbar_f16x2, qbarT_f16x2)");
     if (h0) {
-      TORCH_CHECK_VALUE(!structured && K == 256, "d3pm_mi355x: float16 split tables serve dense tables with K = 256");
+      TORCH_CHECK_VALUE(!structured && (K == 64 || K == 128 || K == 256),
+                        "d3pm_mi355x: float16 split tables serve dense tables with K = 64, 128 or 256");
       for (int i = 5; i < 7; ++i) {
         need_device(tables[i], "float16 split table");
         TORCH_CHECK(tables[i].scalar_type() == at::kHalf, "d3pm_mi355x: split tables are float16");

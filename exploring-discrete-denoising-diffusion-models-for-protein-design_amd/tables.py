@@ -32,13 +32,15 @@ class ImageTables:
     anything else (Gaussian, banded) the dense path with float32 copies.
 
     ``dense_matmul`` picks how the K x K contraction of ``_at_onehot`` runs for
-    dense tables with K = 256: ``"f16x2"`` (default) emulates float32 on the
+    dense tables with K = 64, 128 or 256 (at 64 and 128 in the training loss
+    only): ``"f16x2"`` (default) emulates float32 on the
     float16 matrix instructions -- every operand, scaled into float16's range,
     split into two float16 pieces, three products per term, relative error below
     2^-22 per product (absolute 2^-39 for entries below 2^-16) -- from split
     copies of the cumulative table built here (4 bytes per entry each way);
-    ``"f32"`` uses the float32 matrix instructions (an in-order float32 fma
-    chain).  Other alphabets contract on the vector ALUs in float32 either way.
+    ``"f32"`` uses the float32 matrix instructions at K = 256 (an in-order
+    float32 fma chain) and the vector ALUs otherwise.  Other alphabets contract
+    on the vector ALUs in float32 either way.
     """
 
     def __init__(self, q_mats: torch.Tensor, q_onestep: torch.Tensor, eps: float = 1e-6,
@@ -67,7 +69,7 @@ class ImageTables:
             self.qoneT = ops.table_to_f32(q_onestep.permute(0, 2, 1))
             # the float16 pieces carry 2^14 x the entry: tables of probabilities only (a caller's own q_mats with
             # entries above 1 -- not a transition table -- stay on the float32 instructions; one host read at set-up)
-            if K == 256 and dense_matmul == "f16x2" and float(self.qbar.abs().max()) <= 1.0 + 1e-6:
+            if K in (64, 128, 256) and dense_matmul == "f16x2" and float(self.qbar.abs().max()) <= 1.0 + 1e-6:
                 self.qbar_f16x2 = ops.table_split_f16x2(self.qbar)
                 self.qbarT_f16x2 = ops.table_split_f16x2(self.qbarT)
         self.dense_matmul = dense_matmul if self.qbar_f16x2 is not None else "f32"

@@ -369,22 +369,24 @@ def test_wide_structured_loss_against_oracle(pkg, K, B, npos):
 
 
 @pytest.mark.parametrize("dense_matmul", ["f16x2", "f32"])
-@pytest.mark.parametrize("B,L", [(2, 150), (3, 64), (1, 65), (9, 333)])
-def test_k256_matrix_core_tiles_against_oracle(pkg, B, L, dense_matmul):
+@pytest.mark.parametrize("B,L,bits", [(2, 150, 8), (3, 64, 8), (1, 65, 8), (9, 333, 8), (2, 150, 7), (9, 333, 7), (1, 65, 6),
+                                      (9, 333, 6)])
+def test_k256_matrix_core_tiles_against_oracle(pkg, B, L, bits, dense_matmul):
     """K = 256 runs its contractions on the matrix cores in tiles of 64 tokens:
     several tiles per workgroup, a partial last tile, a single-token tail, a t = 0
     batch element, more batch elements than one round of the XCD mapping.  Both
     contraction paths: 'f16x2' (float32 emulated with two float16 pieces per operand;
     the training loss on the register-tile kernel, everything else on the tile
-    kernel) and 'f32' (the float32 matrix instructions)."""
-    K, T = 256, 20
+    kernel) and 'f32' (the float32 matrix instructions).  K = 64 and 128: the register-tile kernel serves the loss
+    with and without the gradient ('f16x2'), the vector-ALU tile kernel everything else."""
+    K, T = 2 ** bits, 20
     betas = pkg.generate_betas(1e-3, 0.3, T, "linear")
-    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="gaussian", num_bits=8, transition_bands=None,
+    d = pkg.DiscreteDiffusion(betas=betas, transition_mat_type="gaussian", num_bits=bits, transition_bands=None,
                               model_prediction="x_start", model_output="logits", loss_type="hybrid",
                               hybrid_coeff=0.01, device=DEV)
     d.dense_matmul = dense_matmul
     assert (d.tables().qbar_f16x2 is not None) == (dense_matmul == "f16x2")
-    p = im.build_process(betas, "gaussian", 8, None, hybrid_coeff=0.01)
+    p = im.build_process(betas, "gaussian", bits, None, hybrid_coeff=0.01)
     gen = torch.Generator().manual_seed(1000 * B + L)
     x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen)
     t = torch.randint(1, T, (B,), generator=gen, dtype=torch.int32)
@@ -404,6 +406,9 @@ def test_k256_matrix_core_tiles_against_oracle(pkg, B, L, dense_matmul):
         close(loss, loss_ref.detach().numpy(), atol=LOSS_ATOL, what=f"loss {lt}")
         ref = lg_ref.grad.numpy()
         close(lg.grad, ref, rtol=RTOL, atol=GRAD_FLOOR * np.abs(ref).max(), what=f"grad {lt}")
+        with torch.no_grad():                                  # forward only: its own kernel instantiation
+            loss_f = d.training_losses(lambda x, tt: logits.to(DEV), x_start=x0.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+        close(loss_f, loss_ref.detach().numpy(), atol=LOSS_ATOL, what=f"forward-only loss {lt}")
     d.loss_type = "hybrid"
     post = d.q_posterior_logits(logits.to(DEV), xt_ref.to(DEV), t.to(DEV), x_start_logits=True)
     close(post, im.posterior_logits(p, logits, xt_ref, t, True).numpy(), atol=POST_ATOL, what="posterior logits")
