@@ -408,6 +408,139 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
   }
 }
 
+// p_sample (d3pm/diffusion_discrete.py:384-403) with noise drawn on the device and no probabilities asked for, on
+// the same register tile: softmax -> contraction -> posterior weights (a_j + eps)(f2_j + eps) -> one uniform per
+// token and an inverse CDF over the token's classes in (lane, element) order.  t == 0: the argmax of the logits
+// (first index on ties), as with explicit noise.  The draw consumes word x of Philox4x32-10 keyed (token index,
+// offset, seed), as the tile kernel's does; the class order of the cumulative sums differs from that kernel's, so the
+// two draw different (equally distributed) tokens from one stream.
+template <int K>
+__global__ __launch_bounds__(256, 2) void k_dense_sample256(ImgArgs a, DenseExtra e) {
+  extern __shared__ __align__(16) char ring[];
+  constexpr int NMT = K / 16;
+  constexpr int RT_TABLE = RtCfg<K>::TABLE;
+  const float eps = a.tb.eps;
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int b = (within / a.chunks) * 8 + xcd, chunk = within % a.chunks;
+  if (b >= e.B) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tok = lane & 15, kg = lane >> 4;
+  const int t = __builtin_amdgcn_readfirstlane(load_index(a.t, b, a.t_bytes, a.tb.T));
+  const bool need_post = t > 0;
+  const char* tableF = need_post ? reinterpret_cast<const char*>(a.tb.qbar_f16x2) + (size_t)(t - 1) * RT_TABLE : nullptr;
+  if (e.offset_dev) e.offset += *e.offset_dev;
+  const long p1 = min(a.npos, (chunk + 1) * a.chunk_pos);
+  __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
+  if (need_post) ring_begin<K>(tableF, ring);
+  for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += 64) {
+    const long pos = tile0 + 16 * wave + tok;
+    const bool live = pos < p1;
+    const long n = (long)b * a.npos + (live ? pos : tile0);
+    const int xt = load_index(a.xt, n, a.xt_bytes, K);
+    const long row0 = (long)b * a.npos + tile0;
+    const int rows = (int)min((long)64, p1 - tile0);
+    const __amdgpu_buffer_rsrc_t zrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.logits) + row0 * K, 0, rows * K * 4, 0x00020000);
+    const int rowoff = (live ? 16 * wave + tok : 0) * (K * 4) + 16 * kg;
+    auto load_row4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, int mt) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64 * mt, 0, 0));
+    };
+    f32x4 v[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) v[mt] = load_row4(zrs, rowoff, mt);
+    int pick;
+    if (!need_post) {
+      // argmax of the logits, first index on ties: element order within the lane is not class order across lanes, so
+      // ties are broken on the class index explicitly
+      float best = v[0][0];
+      int bc = 4 * kg;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * kg + r;
+          if (v[mt][r] > best) { best = v[mt][r]; bc = c; }       // (classes ascend within the lane: > keeps the first)
+        }
+#pragma unroll
+      for (int d = 16; d <= 32; d <<= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oc = __shfl_xor(bc, d);
+        if (ob > best || (ob == best && oc < bc)) { best = ob; bc = oc; }
+      }
+      pick = bc;
+    } else {
+      float m = v[0][0];
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, v[mt][r]);
+      m = quad_lanes_max(m);
+      float sum = 0;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[mt][r] = fast_exp2((v[mt][r] - m) * LOG2E); sum += v[mt][r]; }
+      sum = quad_lanes_sum(sum);
+      const float pscale = live ? fast_rcp(sum) * RT_SCALE : 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) v[mt] *= pscale;
+      f32x4 f2[NMT];
+      regtile_contract<K>(tableF, ring, v, f2);
+      if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
+      const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.tb.qoneT) + (size_t)t * K * K, 0, K * K * 4, 0x00020000);
+      const int aoff = xt * (K * 4) + 16 * kg;
+      float lane_tot = 0;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const f32x4 av = load_row4(ars, aoff, mt) + eps;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f2[mt][r] = av[r] * fmaf(f2[mt][r], 1.0f / (RT_SCALE * RT_SCALE), eps);      // the class's weight
+          lane_tot += f2[mt][r];
+        }
+      }
+      // the four lanes' totals, in lane order
+      float before = 0, total = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tk = __shfl(lane_tot, tok + 16 * k);
+        total += tk;
+        before += (k < kg) ? tk : 0.0f;
+      }
+      const U4 rnd = philox4x32_10((uint64_t)n, e.offset, e.seed);
+      const float target = u01_open(rnd.x) * total;
+      float run = before;
+      int key = 0x7fffffff;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          run += f2[mt][r];
+          if (key == 0x7fffffff && f2[mt][r] > 0 && target < run) key = kg * (K / 4) + 4 * mt + r;
+        }
+      key = min(key, __shfl_xor(key, 16));
+      key = min(key, __shfl_xor(key, 32));
+      const int kk = key / (K / 4), el = key % (K / 4);
+      pick = key == 0x7fffffff ? xt : 16 * (el >> 2) + 4 * kk + (el & 3);
+    }
+    if (kg == 0 && live) e.sample[n] = pick;
+  }
+}
+
+template <int K>
+static int launch_sample256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
+  auto kern = k_dense_sample256<K>;
+  const int sh = (RtCfg<K>::NS < RT_RING ? RtCfg<K>::NS : RT_RING) * RT_STAGE;
+  hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+  if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  DenseExtra ee = e;
+  ee.B = B;
+  hipLaunchKernelGGL(kern, dim3(((B + 7) / 8) * 8 * a.chunks), dim3(256), sh, s, a, ee);
+  D3PM_LAUNCH_CHECK("k_dense_sample256");
+  return D3PM_OK;
+}
+
 template <int K, bool GRAD>
 static int launch_loss256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   auto kern = k_dense_loss256<K, GRAD>;

@@ -551,7 +551,7 @@ def test_graphed_bpd_sweep(pkg):
     assert r2["vbterms"].shape == (B, T) and torch.isfinite(r2["total"]).all()
 
 
-@pytest.mark.parametrize("kind,bits", [("gaussian", 8), ("gaussian", 6), ("uniform", 5), ("absorbing", 5)])
+@pytest.mark.parametrize("kind,bits", [("gaussian", 8), ("gaussian", 7), ("gaussian", 6), ("uniform", 5), ("absorbing", 5)])
 def test_p_sample_device_noise_distribution(pkg, kind, bits):
     """p_sample with noise drawn on the device (one uniform per token, inverse CDF
     over the posterior on the dense path): class frequencies over many identical
@@ -620,6 +620,46 @@ def test_p_sample_device_noise_structured_wide_alphabets(pkg, kind, bits):
     sz = d._p_sample_from_logits(lg, xz, tz, None, "uniform", want_probs=False)[0]
     assert torch.equal(sz[:2].cpu(), lg[:2].cpu().argmax(-1))
     assert int(sz[1, 5, 0, 0]) == 7
+
+
+@pytest.mark.parametrize("bits", [6, 7])
+def test_p_sample_device_noise_dense_register_tile(pkg, bits):
+    """The sampling loop's call on dense Gaussian tables with 64 / 128 classes (register-tile kernel on the float16
+    split tables): a different row, x_t and timestep per token, ragged position count.  Per class, the count of draws
+    against the sum of the parity-tested posterior probabilities over the tokens (5 sigma of the Poisson-binomial);
+    t = 0 elements are the argmax of the logits (first index on ties); the same generator state repeats the draws."""
+    K, T, B, L = 2 ** bits, 50, 12, 1000 + 37
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(1e-3, 0.2, T, "linear"), transition_mat_type="gaussian",
+                              num_bits=bits, transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    assert d.tables().dense_matmul == "f16x2" and not d.tables().structured
+    gen = torch.Generator().manual_seed(70 + bits)
+    logits = (2.0 * torch.randn(B, L, 1, 1, K, generator=gen)).to(DEV)
+    logits[1, 5, 0, 0, 7] = logits[1, 5, 0, 0, K - 2] = 50.0
+    logits[0, L - 1, 0, 0, 17] = logits[0, L - 1, 0, 0, 6] = 60.0       # a tie whose first index sits on the later lane
+    x_t = torch.randint(0, K, (B, L, 1, 1), generator=gen).to(DEV)
+    t = torch.tensor([0, 0, 1, 2, 3, 7, 12, 20, 33, 41, 49, 5], dtype=torch.int32, device=DEV)
+    out = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        out.append(d._p_sample_from_logits(logits, x_t, t, None, "uniform", want_probs=False)[0])
+    s = out[0]
+    assert torch.equal(out[0], out[1])
+    assert int(s.min()) >= 0 and int(s.max()) < K
+    assert torch.equal(s[:2].cpu(), logits[:2].cpu().argmax(-1))
+    assert int(s[1, 5, 0, 0]) == 7 and int(s[0, L - 1, 0, 0]) == 6
+    post = d.q_posterior_logits(logits[2:], x_t[2:], t[2:], x_start_logits=True)
+    P = torch.softmax(post.double(), -1).reshape(-1, K)
+    cnt = torch.bincount(s[2:].flatten(), minlength=K).double()
+    z = (cnt - P.sum(0)) / (P * (1 - P)).sum(0).clamp_min(1e-12).sqrt()
+    assert float(z.abs().max()) < 5, z
+    # and the draws follow each token's own distribution: mean log-probability of the drawn classes against its
+    # expectation (minus the entropy), 5 sigma
+    lp = torch.log(P.clamp_min(1e-300))
+    got = lp.gather(1, s[2:].reshape(-1, 1)).sum()
+    mean = (P * lp).sum()
+    var = ((P * lp * lp).sum(1) - (P * lp).sum(1) ** 2).sum()
+    assert abs(float(got - mean)) < 5 * float(var.sqrt()), (float(got), float(mean), float(var.sqrt()))
 
 
 def test_raw_ctypes_binding_as_documented(pkg):
