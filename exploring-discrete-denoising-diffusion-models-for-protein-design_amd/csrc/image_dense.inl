@@ -973,15 +973,15 @@ static int dense_p_sample(const d3pm_tables_f32* tb, const float* logits, long l
                           hipStream_t s) {
   const bool vec = aligned16(logits) && ld == tb->K && (noise_kind == D3PM_NOISE_PHILOX || aligned16(noise)) &&
                    (!probs || aligned16(probs)) && aligned16(tb->qbar) && aligned16(tb->qoneT);
-  // 64 or 128 classes with the float16 split tables, device noise, no probabilities out (the sampling loop's call):
-  // the register-tile kernel (at 256 classes the tile kernel below is the faster one for forward-only work)
-  if (vec && tb->qbar_f16x2 && noise_kind == D3PM_NOISE_PHILOX && !probs && (tb->K == 64 || tb->K == 128)) {
+  // 64, 128 or 256 classes with the float16 split tables, device noise, no probabilities out (the sampling loop's
+  // call): the register-tile kernel (76 against 85 us on the tile kernel below at 256 classes, B = 128 x 1024 tokens)
+  if (vec && tb->qbar_f16x2 && noise_kind == D3PM_NOISE_PHILOX && !probs && (tb->K == 64 || tb->K == 128 || tb->K == 256)) {
     ImgArgs a = make_args(tb, nullptr, 8, x_t, xt_bytes, t, t_bytes, B, npos, 1);
     const TokenGrid tg = token_grid(B, npos, 64, 1024);
     a.chunks = tg.chunks; a.chunk_pos = tg.chunk_pos;
     DenseExtra e{};
     e.logits = logits; e.ld = ld; e.seed = seed; e.offset = offset; e.offset_dev = offset_dev; e.sample = sample;
-    return tb->K == 128 ? launch_sample256<128>(a, e, B, s) : launch_sample256<64>(a, e, B, s);
+    return tb->K == 256 ? launch_sample256<256>(a, e, B, s) : tb->K == 128 ? launch_sample256<128>(a, e, B, s) : launch_sample256<64>(a, e, B, s);
   }
   return dispatch_layout(tb->K, vec, [&](auto lay) {
     using L = decltype(lay);

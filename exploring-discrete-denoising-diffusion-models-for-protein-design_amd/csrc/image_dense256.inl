@@ -1,13 +1,14 @@
-// The dense K = 256 training loss (vb_terms_bpd + cross_entropy_start + their
-// gradient, d3pm/diffusion_discrete.py:462-582, for Gaussian and banded
-// transition tables) with every per-token quantity held in registers from the
-// logits load to the gradient store.  Included by image_structured.hip after
+// Dense transition tables (Gaussian, banded) with K = 64, 128 or 256 classes: the
+// training loss (vb_terms_bpd + cross_entropy_start + their gradient,
+// d3pm/diffusion_discrete.py:462-582) and the sampling loop's p_sample
+// (:384-403) with every per-token quantity held in registers from the logits
+// load to the gradient / sample store.  Included by image_structured.hip after
 // image_dense.inl (same translation unit, namespace d3pm).
 //
-// A wave owns 16 tokens.  Lane l = (kg << 4) | tok holds, for token `tok`, the 64
-// classes 16 mt + 4 kg + r (mt = 0..15, r = 0..3): element (mt, r) of every
-// per-class array.  In that order
-//   * a token's row is read and written as sixteen 16-byte pieces per lane;
+// A wave owns 16 tokens.  Lane l = (kg << 4) | tok holds, for token `tok`, the
+// K / 4 classes 16 mt + 4 kg + r (mt = 0..K/16-1, r = 0..3): element (mt, r) of
+// every per-class array.  In that order
+//   * a token's row is read and written as K / 16 16-byte pieces per lane;
 //   * the two K x K contractions run as  out^T = table-image x act^T  on
 //     v_mfma_f32_16x16x32_f16 with the table as the A operand (rows = output
 //     classes) and the wave's activations as the B operand (columns = tokens):
@@ -15,17 +16,18 @@
 //     and elements (2u, .), (2u+1, .) of an input array are the B operand of
 //     reduction block u -- so softmax -> contraction -> KL terms -> contraction
 //     -> softmax backward never leave the lane's registers;
-//   * sums over a token's classes are 63 additions in registers and two
+//   * sums over a token's classes are K / 4 - 1 additions in registers and two
 //     cross-lane steps (lanes tok, tok + 16, tok + 32, tok + 48).
 // float32 is emulated on the float16 matrix pipe as in tile_contract_f16x2 (two
 // pieces per operand, three products); the activations are split once per use
 // by the wave that owns them.  The table (d3pm_table_split_f16x2's operand image,
-// 256 KB per timestep and orientation) streams from L2 through a four-stage LDS
-// ring of 16 KB stages shared by the workgroup's four waves, one barrier per
-// stage; a stage is 8 output-class tiles x 2 pieces x 1 KB, byte for byte the
-// image in global memory, and a wave's A-operand read is 1 KB of consecutive
-// bytes (no bank conflicts).  64 KB of LDS and at most 256 registers: two
-// workgroups per CU, one's per-token arithmetic under the other's contraction.
+// 4 K^2 bytes per timestep and orientation: 256 KB at K = 256) streams from L2
+// through a four-stage LDS ring of 16 KB stages shared by the workgroup's four
+// waves, one barrier per stage; a stage is 8 output-class tiles x 2 pieces x 1 KB,
+// byte for byte the image in global memory, and a wave's A-operand read is 1 KB
+// of consecutive bytes (no bank conflicts).  At most 64 KB of LDS and 256
+// registers: two workgroups per CU, one's per-token arithmetic under the other's
+// contraction.
 
 namespace d3pm {
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ void ring_barrier() {
   else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
-// out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all 256 classes of `act` taking
+// out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all K classes of `act` taking
 // part (act in element order).  Every wave of the workgroup calls this together, after ring_begin(table).
 //
 // The contraction is a flat sequence of 128 blocks (reduction block u, class tile mt): two 1 KB piece reads and

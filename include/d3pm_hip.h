@@ -147,10 +147,11 @@ typedef struct d3pm_tables_f32 {
   const float* qbar;         /* [T][K][K] q_mats, float32 (dense only)    */
   const float* qoneT;        /* [T][K][K] transpose_q_onestep_mats (dense)*/
   const float* qbarT;        /* [T][K][K] q_mats transposed (dense, for the backward contraction) */
-  /* Optional (both or neither; K = 256): qbar / qbarT as d3pm_table_split_f16x2 writes them.  When present the
-   * K x K contractions of _at_onehot (:242) run as float32 emulated on the float16 matrix instructions (two float16
-   * pieces per operand, three products per term: relative error below 2^-22 per product, against the 2^-24 of a
-   * float32 multiply-add); when NULL, on the float32 matrix instructions. */
+  /* Optional (both or neither; dense tables with K = 64, 128 or 256 whose entries are at most 1): qbar / qbarT as
+   * d3pm_table_split_f16x2 writes them.  When present the K x K contractions of _at_onehot (:242) in the loss and
+   * in p_sample run as float32 emulated on the float16 matrix instructions (two float16 pieces per operand, three
+   * products per term: relative error below 2^-22 per product, against the 2^-24 of a float32 multiply-add); when
+   * NULL, on the float32 matrix instructions (K = 256) or the vector ALUs. */
   const uint16_t* qbar_f16x2;
   const uint16_t* qbarT_f16x2;
 } d3pm_tables_f32;

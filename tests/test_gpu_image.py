@@ -622,9 +622,9 @@ def test_p_sample_device_noise_structured_wide_alphabets(pkg, kind, bits):
     assert int(sz[1, 5, 0, 0]) == 7
 
 
-@pytest.mark.parametrize("bits", [6, 7])
+@pytest.mark.parametrize("bits", [6, 7, 8])
 def test_p_sample_device_noise_dense_register_tile(pkg, bits):
-    """The sampling loop's call on dense Gaussian tables with 64 / 128 classes (register-tile kernel on the float16
+    """The sampling loop's call on dense Gaussian tables with 64 / 128 / 256 classes (register-tile kernel on the float16
     split tables): a different row, x_t and timestep per token, ragged position count.  Per class, the count of draws
     against the sum of the parity-tested posterior probabilities over the tokens (5 sigma of the Poisson-binomial);
     t = 0 elements are the argmax of the logits (first index on ties); the same generator state repeats the draws."""
