@@ -97,6 +97,28 @@ __device__ __forceinline__ void ring_barrier() {
   else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
+// The same with the count as a value (a constant once the caller's loops are unrolled).  n < 0: no stage has to land,
+// the barrier only orders the waves' LDS reads against the next requests.
+__device__ __forceinline__ void ring_barrier_n(int n) {
+  switch (n) {
+#define D3PM_RB(i) case i: ring_barrier<i>(); break;
+    D3PM_RB(0) D3PM_RB(1) D3PM_RB(2) D3PM_RB(3) D3PM_RB(4) D3PM_RB(5) D3PM_RB(6) D3PM_RB(7) D3PM_RB(8) D3PM_RB(9)
+    D3PM_RB(10) D3PM_RB(11) D3PM_RB(12) D3PM_RB(13) D3PM_RB(14) D3PM_RB(15) D3PM_RB(16) D3PM_RB(17) D3PM_RB(18)
+    D3PM_RB(19) D3PM_RB(20) D3PM_RB(21) D3PM_RB(22) D3PM_RB(23) D3PM_RB(24)
+#undef D3PM_RB
+    default:
+      if (n < 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else ring_barrier<0>();
+  }
+}
+// A caller's loads issued from inside the contraction (their latency passes under the matrix instructions; their
+// destination registers are the ones the consumed activations leave free): hook(u, mt) is called once per pair of
+// blocks, issues its loads and returns how many vector-memory instructions that was -- the counted waits of the ring
+// barriers (vector-memory operations complete in order) leave that many more in flight.
+struct NoHook {
+  __device__ __forceinline__ int operator()(int, int) const { return 0; }
+};
+
 // out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all K classes of `act` taking
 // part (act in element order).  Every wave of the workgroup calls this together, after ring_begin(table).
 //
@@ -107,9 +129,9 @@ __device__ __forceinline__ void ring_barrier() {
 // stage's DMA instructions: two stages of cover) and is read from the end of stage s - 1 on: the piece reads run two
 // blocks ahead of the matrix instructions and cross the stage boundaries, so neither a barrier nor an LDS latency
 // sits between two stages' matrix instructions.
-template <int K>
+template <int K, class Hook = NoHook>
 __device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring,
-                                                 const f32x4 (&act)[K / 16], f32x4 (&out)[K / 16]) {
+                                                 const f32x4 (&act)[K / 16], f32x4 (&out)[K / 16], Hook hook = Hook()) {
   using C = RtCfg<K>;
   constexpr int NMT = C::NMT, NU = C::NU, NBLK = C::NBLK, RT_NS = C::NS;
   const int lane = threadIdx.x & 63;
@@ -150,6 +172,7 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   __builtin_amdgcn_sched_barrier(0);
   split_f16x2(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].lo);
   __builtin_amdgcn_sched_barrier(0);
+  int ex_prev = 0, ex_cur = 0;       // the hook's loads issued during the previous / the current stage
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const Pieces& b = pc[u & 1];
@@ -157,6 +180,7 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
     for (int mt = 0; mt < NMT; mt += 2) {
       const int j = u * NMT + mt, s = j / RT_BS;              // block (u, mt) is block j of the image; its stage
       if (j % RT_BS == 0 && s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
+      ex_cur += hook(u, mt);
       if (j + 2 < NBLK) {
         fr[(j + 2) % 4] = read_frag(j + 2);
         fr[(j + 3) % 4] = read_frag(j + 3);
@@ -178,15 +202,13 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       }
       // end of a stage: stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be
       // in flight
+      // Issue order behind stage s + 2's DMA (start of stage s - 1, or ring_begin): the hook's loads of stage s - 1,
+      // the DMA of stage s + 3 (start of this stage), the hook's loads of this stage.
       if (j % RT_BS == RT_BS - 2) {
-        const int last = s + RT_LA < RT_NS ? s + RT_LA : RT_NS - 1;      // latest stage requested so far
-        const int pend = last - (s + 2) > 0 ? last - (s + 2) : 0;
-        switch (pend) {                                                  // (compile-time after unrolling)
-          case 0: ring_barrier<0>(); break;
-          case 1: ring_barrier<1 * RT_DMA>(); break;
-          case 2: ring_barrier<2 * RT_DMA>(); break;
-          default: ring_barrier<3 * RT_DMA>(); break;
-        }
+        static_assert(RT_LA == 3, "the count below is written for requests three stages ahead");
+        ring_barrier_n(s + 2 < RT_NS ? ex_prev + (s + RT_LA < RT_NS ? RT_DMA : 0) + ex_cur : -1);
+        ex_prev = ex_cur;
+        ex_cur = 0;
       }
     }
   }
@@ -229,25 +251,41 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
 #endif
   __builtin_amdgcn_s_setprio(D3PM_VALU_PRIO);
   if (need_post) ring_begin<K>(tableF, ring);
+  auto load_row4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, int mt) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64 * mt, 0, 0));
+  };
+  // rows of a tile through descriptors based at the tile's first row (rows are K floats: ld == K here)
+  auto tile_rsrc = [&](const float* base, long tile0) {
+    const long row0 = (long)b * a.npos + tile0;
+    const int rows = (int)max((long)0, min((long)64, p1 - tile0));       // past the chunk's end: no rows, loads return 0
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + row0 * K, 0, rows * K * 4, 0x00020000);
+  };
+  auto tile_rowoff = [&](long tile0) {
+    return (tile0 + 16 * wave + tok < p1 ? 16 * wave + tok : 0) * (K * 4) + 16 * kg;
+  };
+  // The token's logits.  With 256 classes they are requested one tile ahead (training form: under the last
+  // per-token phase of the tile before) and re-read for the softmax backward from inside the second contraction:
+  // 205 -> 194 us at B = 128 x 1024 tokens.  With 64 and 128 classes, whose contractions are a quarter and a
+  // sixteenth as long, the same measured 1 - 2 us slower: there every row is requested where it is needed.
+  constexpr bool AHEAD = K == 256;
+  f32x4 v[NMT];
+  auto request_rows = [&](long tile0) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(e.logits, tile0);
+    const int off = tile_rowoff(tile0);
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) v[mt] = load_row4(rs, off, mt);
+  };
+  if (AHEAD) request_rows(chunk * a.chunk_pos);
   for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += 64) {
     const long pos = tile0 + 16 * wave + tok;
     const bool live = pos < p1;
     const long n = (long)b * a.npos + (live ? pos : tile0);
     const int x0 = load_index(a.x0, n, a.x0_bytes, K);
     const int xt = load_index(a.xt, n, a.xt_bytes, K);
-    // rows of this tile through descriptors based at the tile's first row (rows are K floats: ld == K here)
-    const long row0 = (long)b * a.npos + tile0;
-    const int rows = (int)min((long)64, p1 - tile0);
-    const __amdgpu_buffer_rsrc_t zrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.logits) + row0 * K, 0, rows * K * 4, 0x00020000);
-    const int rowoff = (live ? 16 * wave + tok : 0) * (K * 4) + 16 * kg;
-    auto load_row4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, int mt) {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64 * mt, 0, 0));
-    };
+    const __amdgpu_buffer_rsrc_t zrs = tile_rsrc(e.logits, tile0);
+    const int rowoff = tile_rowoff(tile0);
+    if (!AHEAD) request_rows(tile0);
     // ---- softmax of the token's logits, cross-entropy term
-    f32x4 v[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) v[mt] = load_row4(zrs, rowoff, mt);
     const float zx0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, rowoff - 16 * kg + 4 * x0, 0, 0));
     float m = v[0][0];
 #pragma unroll
@@ -276,7 +314,9 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       else if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
       D3PM_PHASE256(2);
       // ---- KL(q || p) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of Qbar_{t-1} + eps,
-      // f2 += eps), one log per class; d loss / d f2 replaces f2 in its registers
+      // f2 += eps), one log per class; d loss / d f2 replaces f2 in its registers.  (Requesting the two table rows
+      // from inside the contraction, which fits at 64 and 128 classes, measured equal with the gradient and 3 us
+      // slower without at 128 classes.)
       const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(a.tb.qoneT) + (size_t)t * K * K, 0, K * K * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
@@ -331,18 +371,31 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       if constexpr (GRAD) {
         // ---- d loss / d pi = (d loss / d f2) @ Qbar_{t-1}^T, then through the softmax (re-formed from the
         // re-read row with the same max and 1 / sum: bit-identical) plus the cross-entropy term
-        f32x4 gp[NMT];
-        regtile_contract<K>(tableB, ring, f2, gp);
+        // (256 classes: the row is re-read from inside the contraction, four pieces per reduction block of its second half)
+        f32x4 gp[NMT], pi[NMT];
+        regtile_contract<K>(tableB, ring, f2, gp, [&](int u, int mt) {
+          constexpr int NU = K / 32;
+          if (!AHEAD || mt != 0 || u < NU / 2) return 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pi[4 * (u - NU / 2) + k] = load_row4(zrs, rowoff, 4 * (u - NU / 2) + k);
+          return 4;
+        });
+        if (!AHEAD) {
+#pragma unroll
+          for (int mt = 0; mt < NMT; ++mt) pi[mt] = load_row4(zrs, rowoff, mt);
+        }
         if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
+        // the next tile's rows arrive under this tile's last phase.  (Unconditionally: past the chunk's end the
+        // descriptor holds no rows.  Under a condition the previous contents of v would stay live, in scratch,
+        // from the forward contraction to this point.)
+        if (AHEAD) request_rows(tile0 + 64);
         D3PM_PHASE256(4);
-        f32x4 pi[NMT];
         float dot = 0;
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
-          const f32x4 z = load_row4(zrs, rowoff, mt);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pi[mt][r] = fast_exp2((z[r] - m) * LOG2E) * inv;
+            pi[mt][r] = fast_exp2((pi[mt][r] - m) * LOG2E) * inv;
             gp[mt][r] *= unscale;
             dot = fmaf(pi[mt][r], gp[mt][r], dot);
           }
@@ -354,8 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
           float sel[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) sel[r] = ((d & 3) == r) ? w_ce : 0.0f;
-          const __amdgpu_buffer_rsrc_t grs =
-              __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
+          const __amdgpu_buffer_rsrc_t grs = tile_rsrc(e.dlogits, tile0);
 #pragma unroll
           for (int mt = 0; mt < NMT; ++mt) {
             const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
@@ -376,19 +428,22 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
         float sel[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sel[r] = ((d & 3) == r) ? w : 0.0f;
-        const __amdgpu_buffer_rsrc_t grs =
-            __builtin_amdgcn_make_buffer_rsrc(e.dlogits + row0 * K, 0, rows * K * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t grs = tile_rsrc(e.dlogits, tile0);
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
           const float hit = (mt == mt_hit) ? 1.0f : 0.0f;
           f32x4 gz;
+          // (the row again: the probabilities of the softmax above are not kept past the branch, so that in the
+          // other branch their registers are free from the forward contraction on)
+          const f32x4 z = load_row4(zrs, rowoff, mt);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gz[r] = fmaf(-hit, sel[r], (w / RT_SCALE) * v[mt][r]);
+          for (int r = 0; r < 4; ++r) gz[r] = fmaf(-hit, sel[r], w * (fast_exp2((z[r] - m) * LOG2E) * inv));
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gz), grs, rowoff + 64 * mt, 0, 0);
         }
       }
     }
     if (kg == 0 && live) { acc_vb += vb; acc_ce += ce; }
+    if (AHEAD && !(GRAD && need_post)) request_rows(tile0 + 64);
     D3PM_PHASE256(5);
   }
 #ifdef D3PM_TIMELINE
