@@ -29,21 +29,28 @@
 // registers: two workgroups per CU, one's per-token arithmetic under the other's
 // contraction.
 
+#ifndef D3PM_RT_AHEAD
+#define D3PM_RT_AHEAD 3
+#endif
+
 namespace d3pm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RT_BS = 8;               // blocks (class tiles of one reduction block) per ring stage
 constexpr int RT_STAGE = RT_BS * 2 * 1024;    // bytes of one ring stage
-constexpr int RT_DMA = RT_STAGE / 4096;       // DMA instructions per wave and stage
-constexpr int RT_RING = 4;                      // stages in the LDS ring (3 x 24 KB, 6 or 8 x 8 KB, 16 x 4 KB: equal)
-constexpr int RT_LA = RT_RING - 1;            // a stage's DMA is issued this many stages ahead
 constexpr float RT_SCALE = 16384.0f;          // 2^14: what the table image and the forward activations are scaled by
 // K classes: K / 16 class tiles (elements (mt, .) of a lane's arrays), K / 32 reduction blocks, K^2 / 512 blocks of
 // (reduction block, class tile) = K^2 / 4096 ring stages per contraction (256 classes: 16, 128: 4, 64: 1)
+// The ring: four stages (3 x 24 KB, 6 or 8 x 8 KB, 16 x 4 KB measured equal), a stage's DMA issued three stages ahead.
+// (One workgroup of eight waves per CU on tiles of 128 tokens with a ring of nine stages -- half the table stream per
+// token -- measured slower, 213 against 200 us: nothing then runs beside a workgroup's per-token phases.)
 template <int K>
 struct RtCfg {
   static_assert(K == 64 || K == 128 || K == 256, "alphabets of 64, 128 or 256 classes");
+  static constexpr int RING = 4;                                  // stages in the LDS ring
+  static constexpr int LA = RING - 1;                             // a stage's DMA is issued this many stages ahead
+  static constexpr int DMA = RT_STAGE / 4096;                     // DMA instructions per wave and stage
   static constexpr int NMT = K / 16, NU = K / 32, NBLK = NU * NMT, NS = NBLK / RT_BS;
   static constexpr int TABLE = 2 * K * K * 2;                     // bytes of one timestep's operand image
   static constexpr int SPLIT_AT = NMT >= 8 ? NMT - 6 : NMT - 2;   // class tile (pair) after which the next block's pieces are formed
@@ -72,22 +79,24 @@ __device__ __forceinline__ void ring_dma(const __amdgpu_buffer_rsrc_t& trs, char
   int off;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(off));
 #pragma unroll
-  for (int i = 0; i < RT_DMA; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % RT_RING) * RT_STAGE + i * 4096 + wave * 1024), 16, off,
-                                             s * RT_STAGE + i * 4096 + wave * 1024, 0, 0);
+  for (int i = 0; i < RT_STAGE / 4096; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lds_ptr)(ring + (s % 4) * RT_STAGE + (i * 4 + wave) * 1024), 16, off,
+                                             s * RT_STAGE + (i * 4 + wave) * 1024, 0, 0);
 }
 template <int K>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const char* table) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(table), 0, RtCfg<K>::TABLE, 0x00020000);
 }
-// Requests the first three stages of `table`.  Call once every wave of the workgroup is past its last read of the
+// Requests the first stages of `table` (as many as are kept in flight).  Call once every wave of the workgroup is past its last read of the
 // ring (regtile_contract ends with a barrier), as early as the table is known: the stages arrive under whatever the
 // waves do until the contraction.
 template <int K>
 __device__ __forceinline__ void ring_begin(const char* table, char* ring) {
+  using C = RtCfg<K>;
+  static_assert(C::RING == 4, "ring_dma addresses a ring of four stages");
   const __amdgpu_buffer_rsrc_t trs = table_rsrc<K>(table);
 #pragma unroll
-  for (int s = 0; s < RT_LA && s < RtCfg<K>::NS; ++s) ring_dma(trs, ring, s);
+  for (int s = 0; s < C::LA && s < C::NS; ++s) ring_dma(trs, ring, s);
 }
 // Barrier of the ring: waits until all but the wave's `pending` most recent DMA instructions have landed (and its
 // LDS reads have returned), then meets the other waves.  Not __syncthreads(): its fence waits for every DMA.
@@ -104,7 +113,9 @@ __device__ __forceinline__ void ring_barrier_n(int n) {
 #define D3PM_RB(i) case i: ring_barrier<i>(); break;
     D3PM_RB(0) D3PM_RB(1) D3PM_RB(2) D3PM_RB(3) D3PM_RB(4) D3PM_RB(5) D3PM_RB(6) D3PM_RB(7) D3PM_RB(8) D3PM_RB(9)
     D3PM_RB(10) D3PM_RB(11) D3PM_RB(12) D3PM_RB(13) D3PM_RB(14) D3PM_RB(15) D3PM_RB(16) D3PM_RB(17) D3PM_RB(18)
-    D3PM_RB(19) D3PM_RB(20) D3PM_RB(21) D3PM_RB(22) D3PM_RB(23) D3PM_RB(24)
+    D3PM_RB(19) D3PM_RB(20) D3PM_RB(21) D3PM_RB(22) D3PM_RB(23) D3PM_RB(24) D3PM_RB(25) D3PM_RB(26) D3PM_RB(27)
+    D3PM_RB(28) D3PM_RB(29) D3PM_RB(30) D3PM_RB(31) D3PM_RB(32) D3PM_RB(33) D3PM_RB(34) D3PM_RB(35) D3PM_RB(36)
+    D3PM_RB(37) D3PM_RB(38) D3PM_RB(39) D3PM_RB(40)
 #undef D3PM_RB
     default:
       if (n < 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -122,18 +133,20 @@ struct NoHook {
 // out(mt, r) = sum_k table[k][16 mt + 4 kg + r] * act[k] for the lane's token, all K classes of `act` taking
 // part (act in element order).  Every wave of the workgroup calls this together, after ring_begin(table).
 //
-// The contraction is a flat sequence of 128 blocks (reduction block u, class tile mt): two 1 KB piece reads and
+// The contraction is a flat sequence of K^2 / 512 blocks (reduction block u, class tile mt): two 1 KB piece reads and
 // three matrix instructions each.  Stage s = blocks 8 s .. 8 s + 7 sits in ring buffer s % 4; its DMA is issued at
 // the start of stage s - 3 (its buffer's previous content, stage s - 4, was last read before the barrier that ends
 // that stage), must have landed at the barrier that ends stage s - 2 (which waits for all but the most recent
-// stage's DMA instructions: two stages of cover) and is read from the end of stage s - 1 on: the piece reads run two
+// stage's DMA instructions: two stages of cover) and is read from stage s - 1 on: the piece reads run three pairs of
 // blocks ahead of the matrix instructions and cross the stage boundaries, so neither a barrier nor an LDS latency
-// sits between two stages' matrix instructions.
+// sits between two stages' matrix instructions.  (One, two or three pairs ahead: the training loss within 1 %,
+// p_sample at 256 classes 79 / 78 / 75 us.)
 template <int K, class Hook = NoHook>
 __device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring,
                                                  const f32x4 (&act)[K / 16], f32x4 (&out)[K / 16], Hook hook = Hook()) {
   using C = RtCfg<K>;
   constexpr int NMT = C::NMT, NU = C::NU, NBLK = C::NBLK, RT_NS = C::NS;
+  constexpr int RT_RING = C::RING, RT_LA = C::LA, RT_DMA = C::DMA;
   const int lane = threadIdx.x & 63;
   const __amdgpu_buffer_rsrc_t trs = table_rsrc<K>(table);
   auto mm = [&](f32x4& d, const u32x4& x, const u32x4& y) {
@@ -159,34 +172,40 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   // stages 0 and 1 have landed and are visible; later ones may be on their way
   ring_barrier<((RT_LA < RT_NS ? RT_LA : RT_NS) > 2 ? (RT_LA < RT_NS ? RT_LA : RT_NS) - 2 : 0) * RT_DMA>();
   __builtin_amdgcn_s_setprio(0);     // the co-resident workgroup's per-token arithmetic issues ahead of this stream
-  // blocks go in pairs (two class tiles: two independent accumulators, their matrix instructions interleaved);
-  // the piece reads run one pair ahead
-  Frag fr[4];
-  fr[0] = read_frag(0);
-  fr[1] = read_frag(1);
-  // the activations' pieces of reduction block u + 1 are formed in the middle of block u's second stage, pinned
-  // there by scheduling fences (some twenty vector operations that issue under the matrix instructions around them); left
-  // free, the compiler forms all eight blocks' pieces ahead of the loop and spills them
+  // The activations' float16 pieces, all reduction blocks, formed in place of the float32 values before the first
+  // matrix instruction (block by block, so that the allocator can give a block's pieces the registers of its inputs).
   struct Pieces { u32x4 hi, lo; };
-  Pieces pc[2];
+  Pieces pc[NU];
   __builtin_amdgcn_sched_barrier(0);
-  split_f16x2(__builtin_bit_cast(float4, act[0]), __builtin_bit_cast(float4, act[1]), pc[0].hi, pc[0].lo);
-  __builtin_amdgcn_sched_barrier(0);
-  int ex_prev = 0, ex_cur = 0;       // the hook's loads issued during the previous / the current stage
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const Pieces& b = pc[u & 1];
+    split_f16x2(__builtin_bit_cast(float4, act[2 * u]), __builtin_bit_cast(float4, act[2 * u + 1]), pc[u].hi, pc[u].lo);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // blocks go in pairs (two class tiles: two independent accumulators, their matrix instructions interleaved);
+  // the piece reads run AH pairs ahead (an LDS read of 4 KB per wave and pair returns after some 200 cycles with
+  // every wave of the CU reading; a pair's six matrix instructions cover 96)
+  constexpr int AH = D3PM_RT_AHEAD, NF = 2 * (AH + 1);
+  static_assert(NBLK >= 2 * AH, "prologue reads");
+  Frag fr[NF];
+#pragma unroll
+  for (int q = 0; q < 2 * AH; ++q) fr[q] = read_frag(q);
+  __builtin_amdgcn_sched_barrier(0);
+  int ex[RT_NS] = {};                // the hook's loads issued during each stage
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const Pieces& b = pc[u];
 #pragma unroll
     for (int mt = 0; mt < NMT; mt += 2) {
       const int j = u * NMT + mt, s = j / RT_BS;              // block (u, mt) is block j of the image; its stage
       if (j % RT_BS == 0 && s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
-      ex_cur += hook(u, mt);
-      if (j + 2 < NBLK) {
-        fr[(j + 2) % 4] = read_frag(j + 2);
-        fr[(j + 3) % 4] = read_frag(j + 3);
+      ex[s] += hook(u, mt);
+      if (j + 2 * AH < NBLK) {
+        fr[(j + 2 * AH) % NF] = read_frag(j + 2 * AH);
+        fr[(j + 2 * AH + 1) % NF] = read_frag(j + 2 * AH + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const Frag &f0 = fr[j % 4], &f1 = fr[(j + 1) % 4];
+      const Frag &f0 = fr[j % NF], &f1 = fr[(j + 1) % NF];
       f32x4 &d0 = out[mt], &d1 = out[mt + 1];
       mm(d0, f0.lo, b.hi);      // small terms first
       mm(d1, f1.lo, b.hi);
@@ -195,20 +214,19 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       mm(d0, f0.hi, b.hi);
       mm(d1, f1.hi, b.hi);
       __builtin_amdgcn_sched_barrier(0);
-      if (mt == C::SPLIT_AT && u + 1 < NU) {
-        Pieces& nx = pc[(u + 1) & 1];
-        split_f16x2(__builtin_bit_cast(float4, act[2 * u + 2]), __builtin_bit_cast(float4, act[2 * u + 3]), nx.hi, nx.lo);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       // end of a stage: stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be
       // in flight
-      // Issue order behind stage s + 2's DMA (start of stage s - 1, or ring_begin): the hook's loads of stage s - 1,
-      // the DMA of stage s + 3 (start of this stage), the hook's loads of this stage.
+      // Issued behind stage s + 2's DMA (which went out at the start of stage s + 2 - LA, or in ring_begin): the
+      // DMA of the stages after it up to the latest one requested, and the hook's loads from that stage on.
       if (j % RT_BS == RT_BS - 2) {
-        static_assert(RT_LA == 3, "the count below is written for requests three stages ahead");
-        ring_barrier_n(s + 2 < RT_NS ? ex_prev + (s + RT_LA < RT_NS ? RT_DMA : 0) + ex_cur : -1);
-        ex_prev = ex_cur;
-        ex_cur = 0;
+        int n = -1;
+        if (s + 2 < RT_NS) {
+          const int last = s + RT_LA < RT_NS ? s + RT_LA : RT_NS - 1;
+          n = (last - (s + 2)) * RT_DMA;
+#pragma unroll
+          for (int q = (s + 2 - RT_LA > 0 ? s + 2 - RT_LA : 0); q <= s; ++q) n += ex[q];
+        }
+        ring_barrier_n(n);
       }
     }
   }
@@ -220,6 +238,7 @@ template <int K, bool GRAD>
 __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra e) {
   extern __shared__ __align__(16) char ring[];
   __shared__ float red[2 * 4];
+  constexpr int TILE = 64;                      // tokens per tile: 16 per wave
   constexpr int NMT = K / 16;                   // class tiles = 16-byte pieces of a lane's share of a row
   constexpr int RT_TABLE = RtCfg<K>::TABLE;
   const float eps = a.tb.eps;
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
   // rows of a tile through descriptors based at the tile's first row (rows are K floats: ld == K here)
   auto tile_rsrc = [&](const float* base, long tile0) {
     const long row0 = (long)b * a.npos + tile0;
-    const int rows = (int)max((long)0, min((long)64, p1 - tile0));       // past the chunk's end: no rows, loads return 0
+    const int rows = (int)max((long)0, min((long)TILE, p1 - tile0));       // past the chunk's end: no rows, loads return 0
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + row0 * K, 0, rows * K * 4, 0x00020000);
   };
   auto tile_rowoff = [&](long tile0) {
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
     for (int mt = 0; mt < NMT; ++mt) v[mt] = load_row4(rs, off, mt);
   };
   if (AHEAD) request_rows(chunk * a.chunk_pos);
-  for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += 64) {
+  for (long tile0 = chunk * a.chunk_pos; tile0 < p1; tile0 += TILE) {
     const long pos = tile0 + 16 * wave + tok;
     const bool live = pos < p1;
     const long n = (long)b * a.npos + (live ? pos : tile0);
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       f32x4 f2[NMT];
       regtile_contract<K>(tableF, ring, v, f2);
       if (GRAD) ring_begin<K>(tableB, ring);
-      else if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
+      else if (tile0 + TILE < p1) ring_begin<K>(tableF, ring);
       D3PM_PHASE256(2);
       // ---- KL(q || p) with q ~ a.*b, p ~ a.*f2 (a = column x_t of Q_t + eps, b = row x0 of Qbar_{t-1} + eps,
       // f2 += eps), one log per class; d loss / d f2 replaces f2 in its registers.  (Requesting the two table rows
@@ -384,11 +403,11 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
 #pragma unroll
           for (int mt = 0; mt < NMT; ++mt) pi[mt] = load_row4(zrs, rowoff, mt);
         }
-        if (tile0 + 64 < p1) ring_begin<K>(tableF, ring);
+        if (tile0 + TILE < p1) ring_begin<K>(tableF, ring);
         // the next tile's rows arrive under this tile's last phase.  (Unconditionally: past the chunk's end the
         // descriptor holds no rows.  Under a condition the previous contents of v would stay live, in scratch,
         // from the forward contraction to this point.)
-        if (AHEAD) request_rows(tile0 + 64);
+        if (AHEAD) request_rows(tile0 + TILE);
         D3PM_PHASE256(4);
         float dot = 0;
 #pragma unroll
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_loss256(ImgArgs a, DenseExtra 
       }
     }
     if (kg == 0 && live) { acc_vb += vb; acc_ce += ce; }
-    if (AHEAD && !(GRAD && need_post)) request_rows(tile0 + 64);
+    if (AHEAD && !(GRAD && need_post)) request_rows(tile0 + TILE);
     D3PM_PHASE256(5);
   }
 #ifdef D3PM_TIMELINE
@@ -588,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_sample256(ImgArgs a, DenseExtr
 template <int K>
 static int launch_sample256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
   auto kern = k_dense_sample256<K>;
-  const int sh = (RtCfg<K>::NS < RT_RING ? RtCfg<K>::NS : RT_RING) * RT_STAGE;
+  const int sh = (RtCfg<K>::NS < RtCfg<K>::RING ? RtCfg<K>::NS : RtCfg<K>::RING) * RT_STAGE;
   hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   DenseExtra ee = e;
@@ -600,8 +619,9 @@ static int launch_sample256(const ImgArgs& a, const DenseExtra& e, int B, hipStr
 
 template <int K, bool GRAD>
 static int launch_loss256(const ImgArgs& a, const DenseExtra& e, int B, hipStream_t s) {
+  using C = RtCfg<K>;
   auto kern = k_dense_loss256<K, GRAD>;
-  const int sh = (RtCfg<K>::NS < RT_RING ? RtCfg<K>::NS : RT_RING) * RT_STAGE;
+  const int sh = (C::NS < C::RING ? C::NS : C::RING) * RT_STAGE;
   hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
   if (er != hipSuccess) return hip_fail(er, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   DenseExtra ee = e;

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import d3pm_amd
 from d3pm_amd._lib import lib, check, ptr, stream_ptr, LOSS
 
-B, L, K, T = 128, 1024, 256, 1000
+B, L, K, T = int(os.environ.get("TL_B", 128)), 1024, 256, 1000          # TL_B=16: one workgroup per CU
 dev = torch.device("cuda", 0)
 betas = d3pm_amd.generate_betas(1e-4, 0.02, T, "linear")
 d = d3pm_amd.DiscreteDiffusion(betas=betas, transition_mat_type="gaussian", num_bits=8, transition_bands=None,
