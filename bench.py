@@ -735,6 +735,41 @@ def worker(args):
                               "executed_frac_of_f16_peak": 3 * tfl / 2500.0},
                  "f32_matrix_instructions": {"what": "dense_matmul='f32': v_mfma_f32_32x32x2_f32, an in-order float32 fma chain",
                                              "kernel_ms": fms, "achieved": tflf, "peak": 157.3, "frac": tflf / 157.3}}
+        # the sampling loop's reverse step on the same tables (device noise, no probabilities out), and the same two
+        # launches on 7- and 6-bit data (K = 128 / 64, Gaussian Q): the register-tile kernels at their other sizes
+        smpi = torch.empty(BI, 32, 32, 1, dtype=torch.int64, device=dev)
+
+        def dense_sample():
+            check(lib.d3pm_p_sample(tbi.desc(), ptr(lgi), KI, ptr(xti), 8, ptr(ti), 4, BI, LI, None,
+                                    d3pm_amd._lib.NOISE_PHILOX, 1, 0, None, ptr(smpi), None, sp))
+        dense["p_sample"] = {"what": "d3pm_p_sample, device noise, no probabilities out, same tokens",
+                             "kernel_ms": event_ms(dense_sample, 100, warm=20)}
+        narrower = {}
+        for bits in (7, 6):
+            Kn = 2 ** bits
+            dn = d3pm_amd.DiscreteDiffusion(betas=d3pm_amd.generate_betas(1e-4, 0.02, TI, "linear"),
+                                            transition_mat_type="gaussian", num_bits=bits, transition_bands=None,
+                                            model_prediction="x_start", model_output="logits", loss_type="hybrid",
+                                            hybrid_coeff=LAMBDA, device=dev)
+            tbn = dn.tables()
+            x0n = torch.randint(0, Kn, (BI, 32, 32, 1), device=dev)
+            xtn = dn.q_sample(x0n, ti)
+            lgn = torch.randn(BI, 32, 32, 1, Kn, device=dev)
+            dln = torch.empty_like(lgn)
+
+            def loss_n():
+                check(lib.d3pm_hybrid_loss(tbn.desc(), ptr(lgn), Kn, ptr(x0n), 8, ptr(xtn), 8, ptr(ti), 4, BI, LI,
+                                           LOSS["hybrid"], LAMBDA, 1.0 / BI, None, None, None, ptr(lossi), ptr(dln), None,
+                                           None, 0, ptr(wsi), wsbi, sp))
+
+            def sample_n():
+                check(lib.d3pm_p_sample(tbn.desc(), ptr(lgn), Kn, ptr(xtn), 8, ptr(ti), 4, BI, LI, None,
+                                        d3pm_amd._lib.NOISE_PHILOX, 1, 0, None, ptr(smpi), None, sp))
+            lms = event_ms(loss_n, 100, warm=20)
+            narrower[f"K{Kn}"] = {"loss_fwd_bwd_ms": lms, "p_sample_ms": event_ms(sample_n, 100, warm=20),
+                                  "loss_hbm_frac": (8 * Kn + 16) * BI * LI / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del dn, tbn, lgn, dln
+        dense["narrower_alphabets"] = narrower
         if not args.no_cpu_baseline and world == 1:
             image_tables_cpu = (di.q_mats.cpu(), di.transpose_q_onestep_mats.cpu(), di.betas.cpu())
         # three channels (the CIFAR shape of the reference's notebook): B=128 32x32x3, 3072 positions per image

@@ -49,6 +49,10 @@ dense)
   K="$R/tools/kbench.py --kind gaussian --bits 8 --B 128 --L 1024"
   echo "== dense K=256: kernel trace"
   timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o dense -- python3 -u $K --reps 100 > $O/dense.log
+  for bits in 7 6; do
+    echo "== dense K=$((1 << bits)): kernel trace"
+    timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o dense_k$((1 << bits)) -- python3 -u $R/tools/kbench.py --kind gaussian --bits $bits --B 128 --L 1024 --reps 100 > $O/dense_k$((1 << bits)).log
+  done
   echo "== dense K=256: matrix-core counters"
   timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O -o mfma -- python3 -u $K --reps 3 > $O/mfma.log
   sum $O/pmc_mfma.json $O/mfma_counter_collection.csv > $O/pmc_mfma.txt
