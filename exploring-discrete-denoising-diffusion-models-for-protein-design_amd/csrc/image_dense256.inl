@@ -30,7 +30,7 @@
 // contraction.
 
 #ifndef D3PM_RT_AHEAD
-#define D3PM_RT_AHEAD 3
+#define D3PM_RT_AHEAD 2
 #endif
 
 namespace d3pm {
@@ -137,10 +137,9 @@ struct NoHook {
 // three matrix instructions each.  Stage s = blocks 8 s .. 8 s + 7 sits in ring buffer s % 4; its DMA is issued at
 // the start of stage s - 3 (its buffer's previous content, stage s - 4, was last read before the barrier that ends
 // that stage), must have landed at the barrier that ends stage s - 2 (which waits for all but the most recent
-// stage's DMA instructions: two stages of cover) and is read from stage s - 1 on: the piece reads run three pairs of
+// stage's DMA instructions: two stages of cover) and is read from stage s - 1 on: the piece reads run two pairs of
 // blocks ahead of the matrix instructions and cross the stage boundaries, so neither a barrier nor an LDS latency
-// sits between two stages' matrix instructions.  (One, two or three pairs ahead: the training loss within 1 %,
-// p_sample at 256 classes 79 / 78 / 75 us.)
+// sits between two stages' matrix instructions.  (One or two pairs ahead: within 1 %.)
 template <int K, class Hook = NoHook>
 __device__ __forceinline__ void regtile_contract(const char* __restrict__ table, char* ring,
                                                  const f32x4 (&act)[K / 16], f32x4 (&out)[K / 16], Hook hook = Hook()) {
@@ -183,10 +182,12 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
     __builtin_amdgcn_sched_barrier(0);
   }
   // blocks go in pairs (two class tiles: two independent accumulators, their matrix instructions interleaved);
-  // the piece reads run AH pairs ahead (an LDS read of 4 KB per wave and pair returns after some 200 cycles with
-  // every wave of the CU reading; a pair's six matrix instructions cover 96)
+  // the piece reads run AH pairs ahead
   constexpr int AH = D3PM_RT_AHEAD, NF = 2 * (AH + 1);
   static_assert(NBLK >= 2 * AH, "prologue reads");
+  // a wave has 4 (AH + 1) piece reads in flight at most; the counter that s_waitcnt lgkmcnt reads has four bits.
+  // (Three pairs ahead = 16 in flight returned wrong gradients in 0.2 % of the elements of one test.)
+  static_assert(4 * (AH + 1) <= 15, "LDS reads in flight per wave");
   Frag fr[NF];
 #pragma unroll
   for (int q = 0; q < 2 * AH; ++q) fr[q] = read_frag(q);
@@ -200,11 +201,12 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       const int j = u * NMT + mt, s = j / RT_BS;              // block (u, mt) is block j of the image; its stage
       if (j % RT_BS == 0 && s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
       ex[s] += hook(u, mt);
-      if (j + 2 * AH < NBLK) {
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = j + 2 * AH < NBLK;
+      if (more) {
         fr[(j + 2 * AH) % NF] = read_frag(j + 2 * AH);
         fr[(j + 2 * AH + 1) % NF] = read_frag(j + 2 * AH + 1);
       }
-      __builtin_amdgcn_sched_barrier(0);
       const Frag &f0 = fr[j % NF], &f1 = fr[(j + 1) % NF];
       f32x4 &d0 = out[mt], &d1 = out[mt + 1];
       mm(d0, f0.lo, b.hi);      // small terms first
@@ -213,6 +215,16 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       mm(d1, f1.hi, b.lo);
       mm(d0, f0.hi, b.hi);
       mm(d1, f1.hi, b.hi);
+      // issue order: each of the four piece reads behind a matrix instruction, in its shadow (four reads in a row
+      // ahead of six matrix instructions in a row cost the sum of the two)
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // end of a stage: stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be
       // in flight
