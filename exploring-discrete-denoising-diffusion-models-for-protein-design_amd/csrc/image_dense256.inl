@@ -185,8 +185,7 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
   // the piece reads run AH pairs ahead
   constexpr int AH = D3PM_RT_AHEAD, NF = 2 * (AH + 1);
   static_assert(NBLK >= 2 * AH, "prologue reads");
-  // a wave has 4 (AH + 1) piece reads in flight at most; the counter that s_waitcnt lgkmcnt reads has four bits.
-  // (Three pairs ahead = 16 in flight returned wrong gradients in 0.2 % of the elements of one test.)
+  // a wave has 4 (AH + 1) piece reads in flight at most; the counter that s_waitcnt lgkmcnt reads has four bits
   static_assert(4 * (AH + 1) <= 15, "LDS reads in flight per wave");
   Frag fr[NF];
 #pragma unroll
@@ -201,12 +200,15 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       const int j = u * NMT + mt, s = j / RT_BS;              // block (u, mt) is block j of the image; its stage
       if (j % RT_BS == 0 && s + RT_LA < RT_NS) ring_dma(trs, ring, s + RT_LA);
       ex[s] += hook(u, mt);
-      __builtin_amdgcn_sched_barrier(0);
-      const bool more = j + 2 * AH < NBLK;
-      if (more) {
+      // The four piece reads go out in a row, ahead of the pair's six matrix instructions, and the fence keeps them
+      // there.  Issued one by one between the matrix instructions (sched_group_barrier) the kernel was 1 % faster and
+      // WRONG: at full size 1 - 3 % of the gradient elements differed from launch to launch -- a read's destination
+      // registers had been operands of a matrix instruction issued just before it.
+      if (j + 2 * AH < NBLK) {
         fr[(j + 2 * AH) % NF] = read_frag(j + 2 * AH);
         fr[(j + 2 * AH + 1) % NF] = read_frag(j + 2 * AH + 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
       const Frag &f0 = fr[j % NF], &f1 = fr[(j + 1) % NF];
       f32x4 &d0 = out[mt], &d1 = out[mt + 1];
       mm(d0, f0.lo, b.hi);      // small terms first
@@ -215,16 +217,6 @@ __device__ __forceinline__ void regtile_contract(const char* __restrict__ table,
       mm(d1, f1.hi, b.lo);
       mm(d0, f0.hi, b.hi);
       mm(d1, f1.hi, b.hi);
-      // issue order: each of the four piece reads behind a matrix instruction, in its shadow (four reads in a row
-      // ahead of six matrix instructions in a row cost the sum of the two)
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      }
       __builtin_amdgcn_sched_barrier(0);
       // end of a stage: stage s + 2 has landed (the piece reads reach it before the next barrier); later ones may be
       // in flight

@@ -662,6 +662,60 @@ def test_p_sample_device_noise_dense_register_tile(pkg, bits):
     assert abs(float(got - mean)) < 5 * float(var.sqrt()), (float(got), float(mean), float(var.sqrt()))
 
 
+@pytest.mark.parametrize("bits", [8, 7, 6])
+def test_split_contraction_against_float32_path_full_size(pkg, bits):
+    """Dense Gaussian tables at the bench's size (64 x 1024 tokens, two rounds of workgroups on every CU): the
+    training loss and its gradient on the float16 split tables (register-tile kernel) against the same call on the
+    float32 tables (dense_matmul='f32': float32 matrix instructions at 256 classes, vector ALUs below), both
+    parity-tested against the oracle at small sizes.  Every element, 2e-5 relative with a floor of 1e-6 of the
+    largest gradient; three draws of the inputs.  Repeated launches (loss, gradient, sampled tokens) are bit-identical:
+    a schedule of the contraction whose LDS reads overtook matrix instructions once passed every small case and
+    changed 1 - 3 % of the gradient elements from launch to launch at this size."""
+    from d3pm_amd.tables import ImageTables
+    K, T, B, L = 2 ** bits, 40, 64, 1024
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(1e-3, 0.2, T, "linear"), transition_mat_type="gaussian",
+                              num_bits=bits, transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.01, device=DEV)
+    tb16 = d.tables()
+    assert tb16.dense_matmul == "f16x2"
+    tb32 = ImageTables(d.q_mats, d.transpose_q_onestep_mats, eps=d.eps, transposed_onestep=True, dense_matmul="f32")
+    lib, ptr, check, sp = pkg._lib.lib, pkg._lib.ptr, pkg._lib.check, pkg._lib.stream_ptr()
+    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+    ws = torch.empty(max(wsb // 4, 1), device=DEV)
+    for seed in range(3):
+        gen = torch.Generator().manual_seed(100 * bits + seed)
+        x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen).to(DEV)
+        t = torch.randint(0, T, (B,), generator=gen).to(torch.int32).to(DEV)
+        xt = d.q_sample(x0, t)
+        logits = (2.0 * torch.randn(B, L, 1, 1, K, generator=gen)).to(DEV)
+        res = []
+        for tb in (tb16, tb32, tb16, tb16):
+            loss = torch.empty(B, device=DEV)
+            dl = torch.full_like(logits, float("nan"))
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                       pkg._lib.LOSS["hybrid"], 0.01, 1.0 / B, None, None, None, ptr(loss), ptr(dl),
+                                       None, None, 0, ptr(ws), wsb, sp))
+            res.append((loss, dl))
+        torch.cuda.synchronize()
+        (l16, g16), (l32, g32) = res[:2]
+        assert torch.isfinite(g16).all()
+        torch.testing.assert_close(l16, l32, rtol=2e-5, atol=0)
+        torch.testing.assert_close(g16, g32, rtol=2e-5, atol=1e-6 * float(g32.abs().max()))
+        # a launch's result does not depend on timing: repeated launches are bit-identical
+        for l, g in res[2:]:
+            assert torch.equal(l, l16) and torch.equal(g, g16)
+        # the sampling loop's reverse step on the same tables: the same stream draws the same tokens, launch after launch
+        draws = []
+        for _ in range(3):
+            smp = torch.empty(B, L, 1, 1, dtype=torch.int64, device=DEV)
+            check(lib.d3pm_p_sample(tb16.desc(), ptr(logits), K, ptr(xt), 8, ptr(t), 4, B, L, None,
+                                    pkg._lib.NOISE_PHILOX, 5, 0, None, ptr(smp), None, sp))
+            draws.append(smp)
+        torch.cuda.synchronize()
+        assert torch.equal(draws[0], draws[1]) and torch.equal(draws[0], draws[2])
+        assert int(draws[0].min()) >= 0 and int(draws[0].max()) < K
+
+
 def test_raw_ctypes_binding_as_documented(pkg):
     """The binding a maintainer of the reference would write (plain ctypes, no
     helper of this package): digests from the float64 tables, then the fused loss
