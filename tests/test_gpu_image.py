@@ -704,6 +704,30 @@ def test_split_contraction_against_float32_path_full_size(pkg, bits):
         # a launch's result does not depend on timing: repeated launches are bit-identical
         for l, g in res[2:]:
             assert torch.equal(l, l16) and torch.equal(g, g16)
+        # forward only (another kernel at 256 classes), and the reverse step with probabilities out
+        fw = []
+        for tb in (tb16, tb32, tb16):
+            loss = torch.empty(B, device=DEV)
+            check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                       pkg._lib.LOSS["hybrid"], 0.01, 1.0 / B, None, None, None, ptr(loss), None,
+                                       None, None, 0, ptr(ws), wsb, sp))
+            fw.append(loss)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(fw[0], fw[1], rtol=2e-5, atol=0)
+        torch.testing.assert_close(fw[0], l16, rtol=2e-6, atol=0)
+        assert torch.equal(fw[0], fw[2])
+        if seed == 0:
+            pr = []
+            for tb in (tb16, tb32, tb16):
+                smp = torch.empty(B, L, 1, 1, dtype=torch.int64, device=DEV)
+                probs = torch.full_like(logits, float("nan"))
+                check(lib.d3pm_p_sample(tb.desc(), ptr(logits), K, ptr(xt), 8, ptr(t), 4, B, L, None,
+                                        pkg._lib.NOISE_PHILOX, 5, 0, None, ptr(smp), ptr(probs), sp))
+                pr.append((smp, probs))
+            torch.cuda.synchronize()
+            torch.testing.assert_close(pr[0][1], pr[1][1], rtol=2e-5, atol=1e-9)
+            assert torch.equal(pr[0][1], pr[2][1]) and torch.equal(pr[0][0], pr[2][0])
+            del pr, probs
         # the sampling loop's reverse step on the same tables: the same stream draws the same tokens, launch after launch
         draws = []
         for _ in range(3):
