@@ -740,6 +740,55 @@ def test_split_contraction_against_float32_path_full_size(pkg, bits):
         assert int(draws[0].min()) >= 0 and int(draws[0].max()) < K
 
 
+@pytest.mark.parametrize("kind,bits", [("uniform", 5), ("absorbing", 5), ("uniform", 8), ("absorbing", 7)])
+def test_structured_loss_repeatable_at_bench_size(pkg, kind, bits):
+    """The fused loss on structured tables at the bench's size (256 x 512 tokens): three launches on the same inputs
+    give bit-identical per-element losses and gradients (nothing in a launch depends on timing), and so does the
+    launch that also draws the next batch's timesteps and corruption from a fixed stream."""
+    K, T, B, L = 2 ** bits, 500, 256, 512
+    d = pkg.DiscreteDiffusion(betas=pkg.generate_betas(0.0, 0.0, T, "jsd"), transition_mat_type=kind, num_bits=bits,
+                              transition_bands=None, model_prediction="x_start", model_output="logits",
+                              loss_type="hybrid", hybrid_coeff=0.001, device=DEV)
+    tb = d.tables()
+    assert tb.structured
+    lib, ptr, check, sp = pkg._lib.lib, pkg._lib.ptr, pkg._lib.check, pkg._lib.stream_ptr()
+    gen = torch.Generator().manual_seed(bits)
+    x0 = torch.randint(0, K, (B, L, 1, 1), generator=gen).to(DEV)
+    t = torch.randint(0, T, (B,), generator=gen).to(torch.int32).to(DEV)
+    xt = d.q_sample(x0, t)
+    logits = torch.randn(B, L, 1, 1, K, generator=gen).to(DEV)
+    wsb = lib.d3pm_hybrid_loss_workspace(B, L, K)
+    ws = torch.empty(max(wsb // 4, 1), device=DEV)
+    res = []
+    for _ in range(3):
+        loss = torch.empty(B, device=DEV)
+        dl = torch.full_like(logits, float("nan"))
+        check(lib.d3pm_hybrid_loss(tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L,
+                                   pkg._lib.LOSS["hybrid"], 0.001, 1.0 / B, None, None, None, ptr(loss), ptr(dl), None,
+                                   None, 0, ptr(ws), wsb, sp))
+        res.append((loss, dl))
+    torch.cuda.synchronize()
+    assert torch.isfinite(res[0][1]).all()
+    for l, g in res[1:]:
+        assert torch.equal(l, res[0][0]) and torch.equal(g, res[0][1])
+    if K == 32:
+        nxt = []
+        for _ in range(3):
+            loss = torch.empty(B, device=DEV)
+            dl = torch.full_like(logits, float("nan"))
+            t_nx = torch.empty(B, dtype=torch.int32, device=DEV)
+            xt_nx = torch.empty(B, L, 1, 1, dtype=torch.int64, device=DEV)
+            check(lib.d3pm_hybrid_loss_then_q_sample(
+                tb.desc(), ptr(logits), K, ptr(x0), 8, ptr(xt), 8, ptr(t), 4, B, L, pkg._lib.LOSS["hybrid"], 0.001,
+                1.0 / B, None, None, None, ptr(loss), ptr(dl), ptr(ws), wsb, ptr(x0), 8, 3, 0, None, ptr(t_nx),
+                ptr(xt_nx), sp))
+            nxt.append((loss, dl, t_nx, xt_nx))
+        torch.cuda.synchronize()
+        assert torch.equal(nxt[0][1], res[0][1]) and torch.equal(nxt[0][0], res[0][0])
+        for r in nxt[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(r, nxt[0]))
+
+
 def test_raw_ctypes_binding_as_documented(pkg):
     """The binding a maintainer of the reference would write (plain ctypes, no
     helper of this package): digests from the float64 tables, then the fused loss
